@@ -1,0 +1,124 @@
+"""Loads libfirework_hip.so (HIP kernels + C ABI) and wraps its entry points.
+
+There is deliberately NO fallback: if the shared library is missing, fails to load, or no GPU is
+visible, every call raises.  The CPU oracle under oracle/ is test infrastructure and is never
+reachable from here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfirework_hip.so")
+_lib = None
+
+
+class FireworkError(RuntimeError):
+    def __init__(self, status, detail=""):
+        self.status = status
+        super().__init__(f"firework_hip error {status}: {detail}")
+
+
+def load():
+    """Load the native library once.  torch is imported first so that the process holds exactly one
+    HIP runtime (torch bundles libamdhip64.so.7; our library's DT_NEEDED resolves to that copy)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FireworkError(A.FW_ERR_NO_DEVICE, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`"
+                            " (or `make`) — there is no CPU fallback")
+    if os.environ.get("FIREWORK_NO_TORCH", "0") != "1":
+        import torch  # noqa: F401  (plumbing: one HIP runtime per process, streams, torch.distributed)
+    lib = C.CDLL(LIB_PATH)
+    lib.fw_abi_version.restype = C.c_int
+    lib.fw_strerror.restype = C.c_char_p
+    lib.fw_strerror.argtypes = [C.c_int]
+    lib.fw_last_error.restype = C.c_char_p
+    lib.fw_device_count.restype = C.c_int
+    lib.fw_scene_create.restype = C.c_int
+    lib.fw_scene_create.argtypes = [C.POINTER(A.fw_scene_desc), C.c_int, C.POINTER(C.c_void_p)]
+    lib.fw_scene_destroy.restype = None
+    lib.fw_scene_destroy.argtypes = [C.c_void_p]
+    lib.fw_render.restype = C.c_int
+    lib.fw_render.argtypes = [C.c_void_p, C.POINTER(A.fw_render_params), C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.POINTER(A.fw_stats)]
+    lib.fw_render_scene.restype = C.c_int
+    lib.fw_render_scene.argtypes = [C.POINTER(A.fw_scene_desc), C.POINTER(A.fw_render_params), C.c_int, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.POINTER(A.fw_stats)]
+    if lib.fw_abi_version() != A.FW_ABI_VERSION:
+        raise FireworkError(A.FW_ERR_BAD_ARG, "ABI version mismatch between _abi.py and libfirework_hip.so")
+    _lib = lib
+    return lib
+
+
+def _check(lib, st):
+    if st != A.FW_OK:
+        raise FireworkError(st, f"{lib.fw_strerror(st).decode()} | {lib.fw_last_error().decode()}")
+
+
+def device_count():
+    return load().fw_device_count()
+
+
+class DeviceScene:
+    """An uploaded scene (`fw_scene*`): SoA scene arrays + TLAS/BLAS resident in HBM."""
+
+    def __init__(self, scene_desc, device=0):
+        lib = load()
+        self._lib = lib
+        self._desc = scene_desc  # keep host buffers alive
+        h = C.c_void_p()
+        _check(lib, lib.fw_scene_create(scene_desc.ptr(), device, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def render(self, renderer, pixel_ids=None, out_device_ptrs=None, stream=None):
+        """fw_render.  out_device_ptrs = (rgb8, gamma, linear) raw device pointers (ints or None) to
+        keep results in HBM (multi-GPU gather path); otherwise numpy host arrays are returned."""
+        from .api import RenderResult
+        lib = self._lib
+        p = renderer.to_params(pixel_ids)
+        n = int(pixel_ids.shape[0]) if pixel_ids is not None else p.width * p.height
+        st = A.fw_stats()
+        if out_device_ptrs is not None:
+            p.outputs_on_device = 1
+            p.stream = C.c_void_p(stream) if stream else None
+            ptrs = [C.c_void_p(x) if x else None for x in out_device_ptrs]
+            _check(lib, lib.fw_render(self.handle, C.byref(p), ptrs[0], ptrs[1], ptrs[2], C.byref(st)))
+            return st.as_dict()
+        rgb8 = np.empty((n, 3), np.uint8)
+        gam = np.empty((n, 3), np.float32)
+        lin = np.empty((n, 3), np.float32)
+        _check(lib, lib.fw_render(self.handle, C.byref(p), rgb8.ctypes.data, gam.ctypes.data, lin.ctypes.data,
+                                  C.byref(st)))
+        return RenderResult(rgb8, gam, lin, st.as_dict(), p.width, p.height)
+
+    def close(self):
+        if self.handle:
+            self._lib.fw_scene_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def render_scene(scene_desc, renderer, pixel_ids=None, device=0):
+    """fw_render_scene: the one-shot `Renderer::render(scene)` shape (conversion + BVH + render)."""
+    from .api import RenderResult
+    lib = load()
+    p = renderer.to_params(pixel_ids)
+    n = int(pixel_ids.shape[0]) if pixel_ids is not None else p.width * p.height
+    rgb8 = np.empty((n, 3), np.uint8)
+    gam = np.empty((n, 3), np.float32)
+    lin = np.empty((n, 3), np.float32)
+    st = A.fw_stats()
+    _check(lib, lib.fw_render_scene(scene_desc.ptr(), C.byref(p), device, rgb8.ctypes.data, gam.ctypes.data,
+                                    lin.ctypes.data, C.byref(st)))
+    return RenderResult(rgb8, gam, lin, st.as_dict(), p.width, p.height)

@@ -1,0 +1,1022 @@
+// =============================================================================
+// fw_oracle.cpp — CPU ORACLE.  TEST INFRASTRUCTURE, NOT PRODUCT.
+//
+// A literal CPU restatement of ritobanrc/firework's `Renderer::render()` path
+// (reference src/render.rs and everything it calls), used ONLY as the checker
+// for the HIP path (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline
+// leg).  Nothing under firework_amd/ may import, link or execute this file.
+//
+// Shape of the code follows the reference on purpose: recursive `color()`,
+// pointer-tree BVH that visits both children without narrowing, virtual
+// dispatch per shape / material / texture, one RNG object threaded through
+// every call.  Each function cites the reference file:line it restates.
+//
+// PARITY PINNING: the reference is nightly Rust with eleven
+// un-vendored crates and cannot be built or run here, and it has no tests or
+// golden vectors.  What IS pinned (tests/test_oracle_known_answers.py):
+//   * rotor constructors vs scenes/*.yml values, rotor->matrix vs an
+//     independent geometric-algebra sandwich product;
+//   * hand-derived known answers for every helper (SURVEY §8c list);
+//   * BVH topology counts (N=8 -> 7 nodes, N=968 -> 1023 nodes depth 9, ...);
+//   * coarse block means of the reference's committed cornell_box.png /
+//     suzanne.png / volume.png renders (tests/golden/reference_png_stats.json).
+// What is NOT pinned: bit-level arithmetic of the third-party crates that are
+// absent from /root/reference — `ultraviolet 0.5.1` (Vec3 dot/cross/normalize
+// association, Mat3*Vec3, Rotor3::into_matrix) and `tiny-rng 0.1.0` (LcRng).
+// Those are restated from the crates' published algorithms [recollection,
+// unverified at bit level]; they change results at the 1-ulp level only.
+// => image parity is "pinned coarsely, unpinned at bit level".
+//
+// RNG modes: FW_RNG_LCG keeps the reference's sequential per-pixel stream
+// semantics (render.rs:172); FW_RNG_CTR is the counter-based generator the GPU
+// uses (spec in DESIGN.md §RNG, restated here independently of the device
+// code): every draw is a pure function of (seed, pixel, sample, dimension).
+// =============================================================================
+#include "../include/firework_hip.h"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+// ----------------------------------------------------------------------------
+// ultraviolet::Vec3 (0.5.1, not in tree) — f32 x3
+// dot / cross / mag_sq use mul_add exactly like the crate's macro_rules impl
+// [recollection, unverified]; `/ f32` and normalize divide component-wise.
+// ----------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    float &at(int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+inline V3 v3(const fw_vec3 &v) { return V3{v.x, v.y, v.z}; }
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+inline V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline float dot(V3 a, V3 b) { return std::fmaf(a.x, b.x, std::fmaf(a.y, b.y, a.z * b.z)); }
+inline V3 cross(V3 a, V3 b) {
+    return {std::fmaf(a.y, b.z, -a.z * b.y), std::fmaf(a.z, b.x, -a.x * b.z),
+            std::fmaf(a.x, b.y, -a.y * b.x)};
+}
+inline float mag_sq(V3 a) { return dot(a, a); }
+inline float mag(V3 a) { return std::sqrt(mag_sq(a)); }
+inline V3 normalized(V3 a) { float m = mag(a); return {a.x / m, a.y / m, a.z / m}; }
+inline V3 vmin(V3 a, V3 b) { return {std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)}; }
+inline V3 vmax(V3 a, V3 b) { return {std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)}; }
+
+// ultraviolet::Mat3 — column major; Mat3 * Vec3 = c0*x + c1*y + c2*z, plain mul/add
+struct M3 { V3 c0, c1, c2; };
+inline V3 operator*(const M3 &m, V3 v) {
+    return {m.c0.x * v.x + m.c1.x * v.y + m.c2.x * v.z,
+            m.c0.y * v.x + m.c1.y * v.y + m.c2.y * v.z,
+            m.c0.z * v.x + m.c1.z * v.y + m.c2.z * v.z};
+}
+
+// ultraviolet::Rotor3::into_matrix [recollection; pinned for pure-plane rotors by
+// scenes/*.yml + cornell_box.png and checked in tests against an independent
+// geometric-algebra sandwich product v' = R v R~].
+inline M3 rotor_into_matrix(fw_rotor3 r) {
+    float s2 = r.s * r.s, bxy2 = r.xy * r.xy, bxz2 = r.xz * r.xz, byz2 = r.yz * r.yz;
+    float s_bxy = r.s * r.xy, s_bxz = r.s * r.xz, s_byz = r.s * r.yz;
+    float bxz_byz = r.xz * r.yz, bxy_byz = r.xy * r.yz, bxy_bxz = r.xy * r.xz;
+    M3 m;
+    m.c0 = {s2 - bxy2 - bxz2 + byz2, -2.f * (bxz_byz + s_bxy), 2.f * (bxy_byz - s_bxz)};
+    m.c1 = {2.f * (s_bxy - bxz_byz), s2 - bxy2 + bxz2 - byz2, -2.f * (s_byz + bxy_bxz)};
+    m.c2 = {2.f * (s_bxz + bxy_byz), 2.f * (s_byz - bxy_bxz), s2 + bxy2 - bxz2 - byz2};
+    return m;
+}
+inline fw_rotor3 rotor_reversed(fw_rotor3 r) { return {r.s, -r.xy, -r.xz, -r.yz}; }
+
+// ----------------------------------------------------------------------------
+// RNG.  One object threaded through every call like the reference's `&mut LcRng`.
+// ----------------------------------------------------------------------------
+enum Purpose : uint32_t { P_JITTER = 0, P_LENS = 1, P_SCATTER = 2, P_FRESNEL = 3, P_VOLUME = 4 };
+
+// CTR spec: pcg4d hash (Jarzynski & Olano, JCGT 2020) of
+// (pixel, sample, dimension, seed32); float = (u32 >> 8) * 2^-24 in [0,1).
+inline void pcg4d(uint32_t v[4]) {
+    for (int i = 0; i < 4; i++) v[i] = v[i] * 1664525u + 1013904223u;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+    for (int i = 0; i < 4; i++) v[i] ^= v[i] >> 16;
+    v[0] += v[1] * v[3]; v[1] += v[2] * v[0]; v[2] += v[0] * v[1]; v[3] += v[1] * v[2];
+}
+inline uint32_t ctr_dim(uint32_t purpose, uint32_t segment, uint32_t index) {
+    return purpose | (segment << 3) | (index << 7);
+}
+inline uint32_t fold_seed(uint64_t seed) {
+    return (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u);
+}
+inline float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+
+struct Rng {
+    int mode = FW_RNG_CTR;
+    // LCG: tiny-rng 0.1.0 `LcRng` (NOT in tree) [recollection, unverified]: Knuth MMIX
+    // 64-bit LCG, output = high 32 bits; mapped to [0,1) with the top 24 bits.
+    uint64_t lcg = 0;
+    // CTR key
+    uint32_t seed32 = 0, pixel = 0, sample = 0, segment = 0;
+
+    float lcg_next() {
+        lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+        return u32_to_unit((uint32_t)(lcg >> 32));
+    }
+    // n (<=4) uniform floats for one (purpose, index) dimension of the current segment.
+    void draw(uint32_t purpose, uint32_t index, int n, float *out) {
+        if (mode == FW_RNG_LCG) {
+            for (int i = 0; i < n; i++) out[i] = lcg_next();
+        } else {
+            uint32_t v[4] = {pixel, sample, ctr_dim(purpose, segment, index), seed32};
+            pcg4d(v);
+            for (int i = 0; i < n; i++) out[i] = u32_to_unit(v[i]);
+        }
+    }
+    float draw1(uint32_t purpose, uint32_t index) { float f; draw(purpose, index, 1, &f); return f; }
+};
+
+// util.rs:36-43
+inline V3 random_in_unit_sphere(Rng &rng) {
+    for (uint32_t attempt = 0;; attempt++) {
+        float f[3];
+        rng.draw(P_SCATTER, attempt, 3, f);
+        V3 p = 2.0f * v3(f[0], f[1], f[2]) - v3(1.f, 1.f, 1.f);
+        if (mag_sq(p) < 1.0f) return p;
+    }
+}
+// util.rs:45-52
+inline V3 random_in_unit_disk(Rng &rng) {
+    for (uint32_t attempt = 0;; attempt++) {
+        float f[2];
+        rng.draw(P_LENS, attempt, 2, f);
+        V3 p = 2.0f * v3(f[0], f[1], 0.f) - v3(1.f, 1.f, 0.f);
+        if (dot(p, p) < 1.0f) return p;
+    }
+}
+// util.rs:54-56
+inline V3 reflect(V3 v, V3 n) { return v - 2.f * dot(v, n) * n; }
+// util.rs:58-67
+inline bool refract(V3 v, V3 n, float ni_over_nt, V3 &out) {
+    V3 uv = normalized(v);
+    float dt = dot(uv, n);
+    float disc = 1.f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
+    if (disc > 0.f) { out = ni_over_nt * (uv - n * dt) - n * std::sqrt(disc); return true; }
+    return false;
+}
+// util.rs:69-73
+inline float schlick(float cosine, float ref_idx) {
+    float r0 = (1.f - ref_idx) / (1.f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.f - r0) * std::pow(1.f - cosine, 5.f);
+}
+// util.rs:104-118 — compares SIGNED components (PBRT uses abs)
+inline int max_component_idx(V3 v) {
+    if (v.x > v.y) return (v.z > v.x) ? 2 : 0;
+    return (v.z > v.y) ? 2 : 1;
+}
+// Rust `as u8` / `as u32` / `as usize`: saturating, NaN -> 0
+inline uint8_t sat_u8(float f) { if (!(f > 0.f)) return 0; if (f >= 255.f) return 255; return (uint8_t)f; }
+inline uint32_t sat_u32(float f) { if (!(f > 0.f)) return 0; if (f >= 4294967296.f) return 0xFFFFFFFFu; return (uint32_t)f; }
+inline uint64_t sat_usize(float f) { if (!(f > 0.f)) return 0; if (f >= 18446744073709551616.f) return ~0ull; return (uint64_t)f; }
+
+// ray.rs:5-29 — direction never normalised
+struct Ray { V3 o, d; V3 point(float t) const { return o + t * d; } };
+
+// aabb.rs
+struct AABB {
+    V3 mn, mx;
+    // aabb.rs:30-50
+    bool hit(const Ray &r, float tmin, float tmax) const {
+        for (int a = 0; a < 3; a++) {
+            float inv = 1.f / r.d[a];
+            float t0 = (mn[a] - r.o[a]) * inv;
+            float t1 = (mx[a] - r.o[a]) * inv;
+            if (inv < 0.f) std::swap(t0, t1);
+            tmin = std::fmax(tmin, t0);
+            tmax = std::fmin(tmax, t1);
+            if (!(tmax > tmin)) return false;
+        }
+        return true;
+    }
+    AABB expand(const AABB &o) const { return {vmin(mn, o.mn), vmax(mx, o.mx)}; }           // aabb.rs:52-57
+    V3 center() const { return 0.5f * mn + 0.5f * mx; }                                       // aabb.rs:59-61
+    AABB expand_to_point(V3 p) const { return {vmin(mn, p), vmax(mx, p)}; }                  // aabb.rs:63-68
+    static AABB from_two_points(V3 a, V3 b) { return {vmin(a, b), vmax(a, b)}; }             // aabb.rs:24-28
+};
+
+// render.rs:35-41
+struct Hit { float t; V3 point, normal; int material; float u, v; };
+
+// render.rs:44-47
+struct Hitable {
+    virtual ~Hitable() {}
+    virtual bool hit(const Ray &r, float tmin, float tmax, Rng &rng, Hit &h) const = 0;
+    virtual AABB bounding_box() const = 0;
+};
+
+// objects/mod.rs:19-31
+inline int solve_quadratic(float a, float b, float c, float roots[2]) {
+    float disc = b * b - 4.f * a * c;
+    if (disc < 0.f) return 0;
+    if (disc == 0.f) { roots[0] = -b / (2.f * a); return 1; }
+    roots[0] = (-b - std::sqrt(disc)) / (2.f * a);
+    roots[1] = (-b + std::sqrt(disc)) / (2.f * a);
+    return 2;
+}
+
+constexpr float PI_F = 3.14159265358979323846f;
+
+// objects/sphere.rs:22-29
+inline void sphere_uv(V3 p, float &u, float &v) {
+    float phi = std::atan2(p.z, p.x);
+    float theta = std::asin(p.y);
+    u = 1.f - (phi + PI_F) / (2.f * PI_F);
+    v = (theta + PI_F / 2.f) / PI_F;
+}
+
+// objects/sphere.rs:10-64
+struct Sphere : Hitable {
+    float radius; int material;
+    bool hit(const Ray &r, float tmin, float tmax, Rng &, Hit &h) const override {
+        V3 o = r.o, d = r.d;
+        float a = dot(d, d);
+        float b = 2.f * dot(o, d);
+        float c = dot(o, o) - radius * radius;
+        float roots[2];
+        int n = solve_quadratic(a, b, c, roots);
+        if (n == 0) return false;
+        float t;
+        if (roots[0] < tmax && roots[0] > tmin) t = roots[0];
+        else if (n == 2 && roots[1] < tmax && roots[1] > tmin) t = roots[1];
+        else return false;
+        V3 point = r.point(t);
+        h.t = t; h.point = point; h.normal = point / radius; h.material = material;
+        sphere_uv(point / radius, h.u, h.v);
+        return true;
+    }
+    AABB bounding_box() const override { return {-(v3(1, 1, 1) * radius), v3(1, 1, 1) * radius}; }
+};
+
+// objects/rect.rs:13-86.  a1/a2 = the two in-plane axes, other = the plane's axis
+struct AARect : Hitable {
+    int a1, a2, other;
+    float min_a, min_b, max_a, max_b, k; bool flip_normal; int material;
+    bool hit(const Ray &r, float tmin, float tmax, Rng &, Hit &h) const override {
+        float t = (k - r.o[other]) / r.d[other];
+        if (t < tmin || t > tmax) return false;
+        V3 point = r.point(t);
+        if (point[a1] < min_a || point[a1] > max_a || point[a2] < min_b || point[a2] > max_b) return false;
+        V3 normal = v3(other == 0 ? 1.f : 0.f, other == 1 ? 1.f : 0.f, other == 2 ? 1.f : 0.f);
+        h.t = t; h.point = point; h.normal = flip_normal ? -normal : normal; h.material = material;
+        h.u = (point[a1] - min_a) / (max_a - min_a);
+        h.v = (point[a2] - min_b) / (max_b - min_b);
+        return true;
+    }
+    AABB bounding_box() const override {
+        V3 mn{0, 0, 0}, mx{0, 0, 0};
+        mn.at(a1) = min_a; mn.at(a2) = min_b; mn.at(other) = k - 0.01f;
+        mx.at(a1) = max_a; mx.at(a2) = max_b; mx.at(other) = k + 0.01f;
+        return {mn, mx};
+    }
+};
+inline AARect make_rect(int kind, float a0, float a1v, float b0, float b1, float k, bool flip, int material) {
+    AARect r;
+    if (kind == FW_SHAPE_XYRECT) { r.a1 = 0; r.a2 = 1; r.other = 2; }
+    else if (kind == FW_SHAPE_XZRECT) { r.a1 = 0; r.a2 = 2; r.other = 1; }
+    else { r.a1 = 1; r.a2 = 2; r.other = 0; }
+    r.min_a = a0; r.max_a = a1v; r.min_b = b0; r.max_b = b1; r.k = k; r.flip_normal = flip; r.material = material;
+    return r;
+}
+
+// objects/rect3d.rs:9-105 — faces +z, -z(flip), +y, -y(flip), +x, -x(flip)
+struct Rect3d : Hitable {
+    V3 pos, size; std::vector<AARect> faces;
+    Rect3d(V3 p, V3 s, int m) : pos(p), size(s) {
+        faces.push_back(make_rect(FW_SHAPE_XYRECT, p.x, p.x + s.x, p.y, p.y + s.y, p.z + s.z, false, m));
+        faces.push_back(make_rect(FW_SHAPE_XYRECT, p.x, p.x + s.x, p.y, p.y + s.y, p.z, true, m));
+        faces.push_back(make_rect(FW_SHAPE_XZRECT, p.x, p.x + s.x, p.z, p.z + s.z, p.y + s.y, false, m));
+        faces.push_back(make_rect(FW_SHAPE_XZRECT, p.x, p.x + s.x, p.z, p.z + s.z, p.y, true, m));
+        faces.push_back(make_rect(FW_SHAPE_YZRECT, p.y, p.y + s.y, p.z, p.z + s.z, p.x + s.x, false, m));
+        faces.push_back(make_rect(FW_SHAPE_YZRECT, p.y, p.y + s.y, p.z, p.z + s.z, p.x, true, m));
+    }
+    bool hit(const Ray &r, float tmin, float tmax, Rng &rng, Hit &h) const override {
+        bool any = false; float closest = tmax;
+        for (const AARect &f : faces) {
+            Hit nh;
+            if (f.hit(r, tmin, closest, rng, nh)) { closest = nh.t; h = nh; any = true; }
+        }
+        return any;
+    }
+    AABB bounding_box() const override { return {pos, pos + size}; }
+};
+
+// objects/mesh.rs:12-118
+struct TriangleMesh {
+    std::vector<uint32_t> indices; std::vector<V3> verts;
+    bool has_normals = false, has_uvs = false;
+    std::vector<V3> normals; std::vector<float> uvs; // uvs: 2 per vert
+    int material = 0;
+    size_t num_tris() const { return indices.size() / 3; }
+};
+
+// objects/mesh.rs:120-243
+struct Triangle {
+    const TriangleMesh *mesh; size_t index;
+    bool hit(const Ray &r, float tmin, float tmax, Rng &, Hit &h) const {
+        size_t base = 3 * index;
+        V3 p0 = mesh->verts[mesh->indices[base]], p1 = mesh->verts[mesh->indices[base + 1]],
+           p2 = mesh->verts[mesh->indices[base + 2]];
+        V3 p0t = p0 - r.o, p1t = p1 - r.o, p2t = p2 - r.o;
+        V3 d = r.d;
+        int kz = max_component_idx(d);
+        int kx = (kz + 1) % 3;
+        int ky = (kx + 1) % 3;
+        d = v3(d[kx], d[ky], d[kz]);
+        p0t = v3(p0t[kx], p0t[ky], p0t[kz]);
+        p1t = v3(p1t[kx], p1t[ky], p1t[kz]);
+        p2t = v3(p2t[kx], p2t[ky], p2t[kz]);
+        float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.f / d.z;
+        p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+        p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+        p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+        float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+        float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+        float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+        if ((e0 < 0.f || e1 < 0.f || e2 < 0.f) && (e0 > 0.f || e1 > 0.f || e2 > 0.f)) return false;
+        float det = e0 + e1 + e2;
+        if (det == 0.f) return false;
+        p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+        float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+        if (det < 0.f && (t_scaled >= tmin * det || t_scaled < tmax * det)) return false;
+        else if (det > 0.f && (t_scaled <= tmin * det || t_scaled > tmax * det)) return false;
+        float inv_det = 1.f / det;
+        float b0 = e0 * inv_det, b1 = e1 * inv_det, b2 = e2 * inv_det;
+        float t = t_scaled * inv_det;
+        V3 point = b0 * p0 + b1 * p1 + b2 * p2;
+        float u0 = 0, v0 = 0, u1 = 1, v1 = 0, u2 = 0, v2 = 1;   // mesh.rs:99-109 default uvs
+        if (mesh->has_uvs) {
+            u0 = mesh->uvs[2 * mesh->indices[base]];     v0 = mesh->uvs[2 * mesh->indices[base] + 1];
+            u1 = mesh->uvs[2 * mesh->indices[base + 1]]; v1 = mesh->uvs[2 * mesh->indices[base + 1] + 1];
+            u2 = mesh->uvs[2 * mesh->indices[base + 2]]; v2 = mesh->uvs[2 * mesh->indices[base + 2] + 1];
+        }
+        h.u = b0 * u0 + b1 * u1 + b2 * u2;
+        h.v = b0 * v0 + b1 * v1 + b2 * v2;
+        V3 normal;
+        if (mesh->has_normals) {
+            V3 n0 = mesh->normals[mesh->indices[base]], n1 = mesh->normals[mesh->indices[base + 1]],
+               n2 = mesh->normals[mesh->indices[base + 2]];
+            normal = normalized(b0 * n0 + b1 * n1 + b2 * n2);
+        } else {
+            normal = cross(p0 - p2, p1 - p2);   // unnormalised (mesh.rs:208)
+        }
+        h.t = t; h.point = point; h.normal = normal; h.material = mesh->material;
+        return true;
+    }
+    AABB bounding_box() const {
+        size_t base = 3 * index;
+        V3 p0 = mesh->verts[mesh->indices[base]], p1 = mesh->verts[mesh->indices[base + 1]],
+           p2 = mesh->verts[mesh->indices[base + 2]];
+        AABB aabb = AABB::from_two_points(p0, p1).expand_to_point(p2);
+        V3 size = aabb.mx - aabb.mn;
+        size = v3(std::fabs(size.x), std::fabs(size.y), std::fabs(size.z));
+        if (size.x < 0.001f) { aabb.mn.x -= 0.001f; aabb.mx.x += 0.001f; }
+        if (size.y < 0.001f) { aabb.mn.y -= 0.001f; aabb.mx.y += 0.001f; }
+        if (size.z < 0.001f) { aabb.mn.z -= 0.001f; aabb.mx.z += 0.001f; }
+        return aabb;
+    }
+};
+
+// ----------------------------------------------------------------------------
+// bvh.rs — pointer tree, generic over the item accessor
+// ----------------------------------------------------------------------------
+struct BvhStats { uint32_t nodes = 0, leaves = 0, double_leaves = 0, branches = 0, depth = 0; };
+
+template <class Item> struct BVHNode : Hitable {
+    enum Kind { LEAF, DOUBLE_LEAF, BRANCH } kind;
+    Item a, b;
+    std::unique_ptr<BVHNode> left, right;
+    AABB aabb;
+    // bvh.rs:115-151 — both children, identical [tmin,tmax], min t, tie -> right
+    bool hit(const Ray &r, float tmin, float tmax, Rng &rng, Hit &h) const override {
+        if (!aabb.hit(r, tmin, tmax)) return false;
+        if (kind == LEAF) return a.hit(r, tmin, tmax, rng, h);
+        Hit lh, rh; bool l, rr;
+        if (kind == DOUBLE_LEAF) { l = a.hit(r, tmin, tmax, rng, lh); rr = b.hit(r, tmin, tmax, rng, rh); }
+        else { l = left->hit(r, tmin, tmax, rng, lh); rr = right->hit(r, tmin, tmax, rng, rh); }
+        if (!l && !rr) return false;
+        if (l && !rr) { h = lh; return true; }
+        if (!l && rr) { h = rh; return true; }
+        if (lh.t < rh.t) h = lh; else h = rh;
+        return true;
+    }
+    AABB bounding_box() const override { return aabb; }
+};
+
+struct NanBBox {};
+
+// bvh.rs:21-71
+template <class Item, class GetItem>
+std::unique_ptr<BVHNode<Item>> bvh_new_helper(const GetItem &get, size_t *idx, size_t n, size_t depth, BvhStats &st) {
+    int axis = (int)(depth % 3);
+    // Rust `sort_by` is a stable merge sort; partial_cmp().expect() panics on NaN (bvh.rs:34)
+    for (size_t i = 0; i < n; i++) { float c = get(idx[i]).bounding_box().center()[axis]; if (c != c) throw NanBBox(); }
+    std::stable_sort(idx, idx + n, [&](size_t x, size_t y) {
+        return get(x).bounding_box().center()[axis] < get(y).bounding_box().center()[axis];
+    });
+    auto node = std::make_unique<BVHNode<Item>>();
+    st.nodes++; st.depth = std::max<uint32_t>(st.depth, (uint32_t)depth);
+    if (n == 1) {
+        node->kind = BVHNode<Item>::LEAF; node->a = get(idx[0]); node->b = node->a;
+        node->aabb = node->a.bounding_box(); st.leaves++;
+    } else if (n == 2) {
+        node->kind = BVHNode<Item>::DOUBLE_LEAF; node->a = get(idx[0]); node->b = get(idx[1]);
+        node->aabb = node->a.bounding_box().expand(node->b.bounding_box()); st.double_leaves++;
+    } else {
+        size_t half = n / 2;
+        node->kind = BVHNode<Item>::BRANCH; node->a = get(idx[0]); node->b = node->a;
+        node->left = bvh_new_helper<Item>(get, idx, half, depth + 1, st);
+        node->right = bvh_new_helper<Item>(get, idx + half, n - half, depth + 1, st);
+        node->aabb = node->left->bounding_box().expand(node->right->bounding_box()); st.branches++;
+    }
+    return node;
+}
+// bvh.rs:79-85
+template <class Item, class GetItem>
+std::unique_ptr<BVHNode<Item>> build_bvh(const GetItem &get, size_t n, BvhStats &st) {
+    std::vector<size_t> idx(n);
+    for (size_t i = 0; i < n; i++) idx[i] = i;
+    return bvh_new_helper<Item>(get, idx.data(), n, 0, st);
+}
+
+// mesh.rs:21-30 — a mesh is always its own BVH
+struct MeshHitable : Hitable {
+    std::shared_ptr<TriangleMesh> mesh;
+    std::unique_ptr<BVHNode<Triangle>> root;
+    BvhStats stats;
+    bool hit(const Ray &r, float tmin, float tmax, Rng &rng, Hit &h) const override { return root->hit(r, tmin, tmax, rng, h); }
+    AABB bounding_box() const override { return root->bounding_box(); }
+};
+
+// objects/volume.rs:10-87
+struct ConstantMedium : Hitable {
+    std::unique_ptr<Hitable> obj; float density; int material;
+    uint32_t rng_index = 0;   // CTR-mode dimension: index of the owning render object
+    bool hit(const Ray &r, float tmin, float tmax, Rng &rng, Hit &h) const override {
+        const float FMAX = 3.40282347e+38f;
+        Hit rec1, rec2;
+        if (obj->hit(r, -FMAX, FMAX, rng, rec1)) {
+            if (obj->hit(r, rec1.t + 0.0001f, FMAX, rng, rec2)) {
+                rec1.t = std::fmax(rec1.t, tmin);
+                rec2.t = std::fmin(rec2.t, tmax);
+                if (rec1.t >= rec2.t) return false;
+                rec1.t = std::fmax(rec1.t, 0.f);
+                float dist_inside_boundary = (rec2.t - rec1.t) * mag(r.d);
+                float hit_distance = -(1.f / density) * std::log10(rng.draw1(P_VOLUME, rng_index));  // log10! (volume.rs:67)
+                if (hit_distance < dist_inside_boundary) {
+                    float t = rec1.t + hit_distance / mag(r.d);
+                    h.t = t; h.point = r.point(t); h.normal = v3(0, 1, 0); h.material = material; h.u = 0; h.v = 0;
+                    return true;
+                }
+            }
+        }
+        return false;
+    }
+    AABB bounding_box() const override { return obj->bounding_box(); }
+};
+
+// ----------------------------------------------------------------------------
+// texture.rs
+// ----------------------------------------------------------------------------
+struct Texture { virtual ~Texture() {} virtual V3 sample(float u, float v, V3 p) const = 0; };
+struct ConstantTexture : Texture { V3 color; V3 sample(float, float, V3) const override { return color; } };   // texture.rs:29-34
+struct CheckerTexture : Texture {                                                                               // texture.rs:57-73
+    const Texture *odd, *even; float scale;
+    V3 sample(float u, float v, V3 p) const override {
+        float prod = 1.0f;
+        prod = prod * std::sin(scale * p.x); prod = prod * std::sin(scale * p.y); prod = prod * std::sin(scale * p.z);
+        return !std::signbit(prod) ? even->sample(u, v, p) : odd->sample(u, v, p);
+    }
+};
+// texture.rs:80-106 (Ken Perlin's reference permutation, doubled)
+static const uint16_t PERM[256] = {
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10,
+    23, 190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87,
+    174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211,
+    133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208,
+    89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5,
+    202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119,
+    248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232,
+    178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249,
+    14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205,
+    93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
+inline size_t P(size_t i) { return PERM[i & 255]; }   // P[512] is PERM twice; every index used is <= 511
+inline float fade(float t) { return t * t * (3.f - 2.f * t); }                   // texture.rs:170-173 (smoothstep)
+inline float plerp(float t, float a, float b) { return a + t * (b - a); }        // texture.rs:191-193
+inline float grad(size_t hash, float x, float y, float z) {                      // texture.rs:175-189
+    size_t h = hash & 15;
+    float u = h < 8 ? x : y;
+    float v = h < 4 ? y : ((h == 12 || h == 14) ? x : z);
+    u = (h & 1) == 0 ? u : -u;
+    v = (h & 2) == 0 ? v : -v;
+    return u + v;
+}
+inline float perlin_noise(V3 p) {                                                 // texture.rs:113-158
+    size_t x0 = (size_t)(sat_usize(std::floor(p.x)) & 255), y0 = (size_t)(sat_usize(std::floor(p.y)) & 255),
+           z0 = (size_t)(sat_usize(std::floor(p.z)) & 255);
+    float x = p.x - std::floor(p.x), y = p.y - std::floor(p.y), z = p.z - std::floor(p.z);
+    float u = fade(x), v = fade(y), w = fade(z);
+    size_t a = P(x0) + y0, aa = P(a) + z0, ab = P(a + 1) + z0;
+    size_t b = P(x0 + 1) + y0, ba = P(b) + z0, bb = P(b + 1) + z0;
+    return plerp(w,
+        plerp(v, plerp(u, grad(P(aa), x, y, z), grad(P(ba), x - 1.f, y, z)),
+                 plerp(u, grad(P(ab), x, y - 1.f, z), grad(P(bb), x - 1.f, y - 1.f, z))),
+        plerp(v, plerp(u, grad(P(aa + 1), x, y, z - 1.f), grad(P(ba + 1), x - 1.f, y, z - 1.f)),
+                 plerp(u, grad(P(ab + 1), x, y - 1.f, z - 1.f), grad(P(bb + 1), x - 1.f, y - 1.f, z - 1.f))));
+}
+inline float turb(uint32_t depth, V3 point) {                                     // texture.rs:206-217 (no abs)
+    float accum = 0.f; V3 p = point; float weight = 1.f;
+    for (uint32_t i = 0; i < depth; i++) { accum += weight * perlin_noise(p); weight *= 0.5f; p = p * 2.f; }
+    return accum;
+}
+struct PerlinNoiseTexture : Texture { float scale;                                // texture.rs:161-168
+    V3 sample(float, float, V3 p) const override { float a = perlin_noise(p * scale); return v3(1, 1, 1) * std::fmin(a + 0.5f, 1.f); } };
+struct TurbulenceTexture : Texture { uint32_t depth; float scale;                 // texture.rs:219-225
+    V3 sample(float, float, V3 p) const override { return v3(1, 1, 1) * turb(depth, p * scale); } };
+struct MarbleTexture : Texture { uint32_t depth; float scale;                     // texture.rs:239-249
+    V3 sample(float, float, V3 p) const override {
+        return v3(1, 1, 1) * 0.5f * (1.f + std::sin(scale * p.z + 10.f * turb(depth, p))); } };
+struct ImageTexture : Texture { uint32_t w, h; const uint8_t *rgb;                // texture.rs:296-309
+    V3 sample(float u, float v, V3) const override {
+        float fi = u * (float)w, fj = (1.f - v) * (float)h;
+        uint32_t i = std::min(sat_u32(fi), w - 1), j = std::min(sat_u32(fj), h - 1);
+        const uint8_t *c = rgb + 3 * ((size_t)j * w + i);
+        return v3((float)c[0], (float)c[1], (float)c[2]) / 255.f;
+    } };
+
+// ----------------------------------------------------------------------------
+// material.rs
+// ----------------------------------------------------------------------------
+struct Material {
+    virtual ~Material() {}
+    virtual bool scatter(const Ray &r_in, const Hit &hit, Rng &rng, V3 &atten, Ray &scattered) const = 0;
+    virtual V3 emit(float, float, V3) const { return v3(0, 0, 0); }             // material.rs:13-15
+};
+struct LambertianMat : Material { const Texture *albedo;                          // material.rs:64-75
+    bool scatter(const Ray &, const Hit &hit, Rng &rng, V3 &atten, Ray &sc) const override {
+        V3 target = hit.point + hit.normal + random_in_unit_sphere(rng);
+        sc = Ray{hit.point, target - hit.point};
+        atten = albedo->sample(hit.u, hit.v, hit.point);
+        return true; } };
+struct MetalMat : Material { V3 albedo; float roughness;                          // material.rs:90-107
+    bool scatter(const Ray &r_in, const Hit &hit, Rng &rng, V3 &atten, Ray &sc) const override {
+        V3 reflected = reflect(r_in.d, hit.normal);
+        sc = Ray{hit.point, reflected + roughness * random_in_unit_sphere(rng)};
+        atten = albedo;
+        return dot(sc.d, hit.normal) > 0.f; } };
+struct DielectricMat : Material { float ref_idx;                                  // material.rs:121-151
+    bool scatter(const Ray &r_in, const Hit &hit, Rng &rng, V3 &atten, Ray &sc) const override {
+        V3 reflected = reflect(r_in.d, hit.normal);
+        V3 outward_normal; float ni_over_nt, cosine;
+        if (dot(r_in.d, hit.normal) > 0.f) {
+            outward_normal = -hit.normal; ni_over_nt = ref_idx;
+            cosine = ref_idx * dot(r_in.d, hit.normal) / mag(r_in.d);
+        } else {
+            outward_normal = hit.normal; ni_over_nt = 1.0f / ref_idx;
+            cosine = -dot(r_in.d, hit.normal) / mag(r_in.d);
+        }
+        atten = v3(1, 1, 1);
+        V3 refracted;
+        if (refract(r_in.d, outward_normal, ni_over_nt, refracted)) {
+            if (rng.draw1(P_FRESNEL, 0) > schlick(cosine, ref_idx)) { sc = Ray{hit.point, refracted}; return true; }
+        }
+        sc = Ray{hit.point, reflected};
+        return true; } };
+struct EmissiveMat : Material { const Texture *albedo;                            // material.rs:173-181
+    bool scatter(const Ray &, const Hit &, Rng &, V3 &, Ray &) const override { return false; }
+    V3 emit(float u, float v, V3 p) const override { return albedo->sample(u, v, p); } };
+struct IsotropicMat : Material { const Texture *texture;                          // material.rs:197-204
+    bool scatter(const Ray &, const Hit &hit, Rng &rng, V3 &atten, Ray &sc) const override {
+        atten = texture->sample(hit.u, hit.v, hit.point);
+        sc = Ray{hit.point, random_in_unit_sphere(rng)};
+        return true; } };
+
+// ----------------------------------------------------------------------------
+// environment.rs (+ examples/hdri_test.rs:70-82)
+// ----------------------------------------------------------------------------
+struct Environment { virtual ~Environment() {} virtual V3 sample(V3 dir) const = 0; };
+struct ColorEnv : Environment { V3 color; V3 sample(V3) const override { return color; } };
+struct SkyEnv : Environment { V3 zenith, horizon;
+    V3 sample(V3 dir) const override { float t = 0.5f * (dir.y + 1.0f); return (1.f - t) * horizon + t * zenith; } };
+struct HdrEnv : Environment { uint32_t w, h; const float *rgb;
+    V3 sample(V3 dir) const override {
+        float u, v; sphere_uv(dir, u, v);
+        float width = (float)w, height = (float)h;
+        uint64_t x = sat_usize(u * width), y = sat_usize((1.f - v) * height);
+        uint64_t idx = sat_usize((float)y * width) + x;
+        uint64_t n = (uint64_t)w * h;
+        if (idx >= n) idx = n - 1;   // reference indexes out of bounds (panic) at the poles; clamp instead
+        return v3(rgb[3 * idx], rgb[3 * idx + 1], rgb[3 * idx + 2]);
+    } };
+
+// ----------------------------------------------------------------------------
+// scene.rs
+// ----------------------------------------------------------------------------
+struct RenderObjectInternal {     // scene.rs:165-174
+    std::unique_ptr<Hitable> obj; V3 position; M3 rotation_mat, inv_rotation_mat; bool flip_normals; AABB aabb;
+    // scene.rs:177-212
+    void update_bounding_box() {
+        AABB bbox = obj->bounding_box();
+        float trace = rotation_mat.c0.x + rotation_mat.c1.y + rotation_mat.c2.z;
+        float cos_trace = 0.5f * (trace - 1.f);
+        AABB rotated = bbox;
+        if (cos_trace < 0.999f) {
+            V3 mn = 10e9f * v3(1, 1, 1), mx = -10e9f * v3(1, 1, 1);
+            for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
+                float x = i == 0 ? bbox.mn.x : bbox.mx.x, y = j == 0 ? bbox.mn.y : bbox.mx.y, z = k == 0 ? bbox.mn.z : bbox.mx.z;
+                V3 np = rotation_mat * v3(x, y, z);
+                for (int c = 0; c < 3; c++) { mx.at(c) = std::fmax(np[c], mx[c]); mn.at(c) = std::fmin(np[c], mn[c]); }
+            }
+            rotated = {mn, mx};
+        }
+        aabb = {rotated.mn + position, rotated.mx + position};
+    }
+    // scene.rs:235-266
+    bool hit(const Ray &r, float tmin, float tmax, Rng &rng, Hit &h) const {
+        float trace = rotation_mat.c0.x + rotation_mat.c1.y + rotation_mat.c2.z;
+        float cos_trace = 0.5f * (trace - 1.f);
+        Ray nr = (cos_trace < 0.999f) ? Ray{inv_rotation_mat * (r.o - position), inv_rotation_mat * r.d}
+                                      : Ray{r.o - position, r.d};
+        if (obj->hit(nr, tmin, tmax, rng, h)) {
+            h.point = rotation_mat * h.point;
+            h.point = h.point + position;
+            h.normal = rotation_mat * h.normal;
+            if (flip_normals) h.normal = -h.normal;
+            return true;
+        }
+        return false;
+    }
+    AABB bounding_box() const { return aabb; }
+};
+struct ObjRef {   // `&RenderObjectInternal` as the TLAS item (bvh.rs:88-98)
+    const RenderObjectInternal *p = nullptr;
+    bool hit(const Ray &r, float a, float b, Rng &g, Hit &h) const { return p->hit(r, a, b, g, h); }
+    AABB bounding_box() const { return p->aabb; }
+};
+
+struct SceneInternal : Hitable {     // scene.rs:93-163
+    std::vector<std::unique_ptr<RenderObjectInternal>> render_objects;
+    std::vector<std::unique_ptr<Material>> materials;
+    std::vector<std::unique_ptr<Texture>> textures;
+    std::unique_ptr<Environment> environment;
+    std::vector<std::shared_ptr<TriangleMesh>> meshes;
+    uint32_t blas_nodes = 0;
+    // scene.rs:137-149 — linear closest hit WITH narrowing
+    bool hit(const Ray &r, float tmin, float tmax, Rng &rng, Hit &h) const override {
+        bool any = false; float closest = tmax;
+        for (auto &ro : render_objects) {
+            Hit nh;
+            if (ro->hit(r, tmin, closest, rng, nh)) { closest = nh.t; h = nh; any = true; }
+        }
+        return any;
+    }
+    AABB bounding_box() const override {
+        AABB res = render_objects[0]->aabb;
+        for (size_t i = 1; i < render_objects.size(); i++) res = res.expand(render_objects[i]->aabb);
+        return res;
+    }
+};
+
+struct BuildError { int status; };
+
+std::unique_ptr<Hitable> make_shape(const fw_scene_desc *d, int32_t si, SceneInternal &sc, uint32_t obj_index, int nest) {
+    if (si < 0 || (uint32_t)si >= d->n_shapes || nest > 4) throw BuildError{FW_ERR_BAD_ARG};
+    const fw_shape &s = d->shapes[si];
+    auto chk_mat = [&](int32_t m) { if (m < 0 || (uint32_t)m >= d->n_materials) throw BuildError{FW_ERR_BAD_ARG}; };
+    switch (s.kind) {
+    case FW_SHAPE_SPHERE: { chk_mat(s.material); auto p = std::make_unique<Sphere>(); p->radius = s.radius; p->material = s.material; return p; }
+    case FW_SHAPE_XYRECT: case FW_SHAPE_XZRECT: case FW_SHAPE_YZRECT: {
+        chk_mat(s.material);
+        return std::make_unique<AARect>(make_rect(s.kind, s.a_min, s.a_max, s.b_min, s.b_max, s.k, s.flip_normal != 0, s.material)); }
+    case FW_SHAPE_RECT3D: chk_mat(s.material); return std::make_unique<Rect3d>(v3(s.pos), v3(s.size), s.material);
+    case FW_SHAPE_TRIANGLE_MESH: {
+        chk_mat(s.material);
+        if (!s.verts || !s.indices || s.n_indices == 0 || s.n_indices % 3) throw BuildError{s.n_indices == 0 ? FW_ERR_EMPTY_SCENE : FW_ERR_BAD_ARG};
+        auto m = std::make_shared<TriangleMesh>();
+        m->verts.resize(s.n_verts);
+        for (uint32_t i = 0; i < s.n_verts; i++) m->verts[i] = v3(s.verts[3 * i], s.verts[3 * i + 1], s.verts[3 * i + 2]);
+        m->indices.assign(s.indices, s.indices + s.n_indices);
+        for (uint32_t i : m->indices) if (i >= s.n_verts) throw BuildError{FW_ERR_BAD_ARG};
+        if (s.normals) { m->has_normals = true; m->normals.resize(s.n_verts);
+            for (uint32_t i = 0; i < s.n_verts; i++) m->normals[i] = v3(s.normals[3 * i], s.normals[3 * i + 1], s.normals[3 * i + 2]); }
+        if (s.uvs) { m->has_uvs = true; m->uvs.assign(s.uvs, s.uvs + 2 * (size_t)s.n_verts); }
+        m->material = s.material;
+        auto mh = std::make_unique<MeshHitable>();
+        mh->mesh = m;
+        const TriangleMesh *mp = m.get();
+        mh->root = build_bvh<Triangle>([mp](size_t i) { return Triangle{mp, i}; }, m->num_tris(), mh->stats);
+        sc.blas_nodes += mh->stats.nodes;
+        sc.meshes.push_back(m);
+        return mh; }
+    case FW_SHAPE_CONSTANT_MEDIUM: {
+        chk_mat(s.material);
+        auto cm = std::make_unique<ConstantMedium>();
+        cm->obj = make_shape(d, s.inner, sc, obj_index, nest + 1);
+        cm->density = s.density; cm->material = s.material; cm->rng_index = obj_index;
+        return cm; }
+    default: throw BuildError{FW_ERR_BAD_ARG};
+    }
+}
+
+// scene.rs:111-135, 279-292
+void build_scene(const fw_scene_desc *d, SceneInternal &sc) {
+    if (!d) throw BuildError{FW_ERR_BAD_ARG};
+    if (d->n_objects == 0) throw BuildError{FW_ERR_EMPTY_SCENE};
+    // textures (two passes so Checker can point at any index)
+    sc.textures.resize(d->n_textures);
+    for (uint32_t i = 0; i < d->n_textures; i++) {
+        const fw_texture &t = d->textures[i];
+        switch (t.kind) {
+        case FW_TEX_CONSTANT: { auto p = std::make_unique<ConstantTexture>(); p->color = v3(t.color); sc.textures[i] = std::move(p); break; }
+        case FW_TEX_CHECKER: { auto p = std::make_unique<CheckerTexture>(); p->scale = t.scale; p->odd = p->even = nullptr; sc.textures[i] = std::move(p); break; }
+        case FW_TEX_PERLIN: { auto p = std::make_unique<PerlinNoiseTexture>(); p->scale = t.scale; sc.textures[i] = std::move(p); break; }
+        case FW_TEX_TURBULENCE: { auto p = std::make_unique<TurbulenceTexture>(); p->scale = t.scale; p->depth = t.depth; sc.textures[i] = std::move(p); break; }
+        case FW_TEX_MARBLE: { auto p = std::make_unique<MarbleTexture>(); p->scale = t.scale; p->depth = t.depth; sc.textures[i] = std::move(p); break; }
+        case FW_TEX_IMAGE: { if (!t.img_rgb8 || !t.img_w || !t.img_h) throw BuildError{FW_ERR_BAD_ARG};
+            auto p = std::make_unique<ImageTexture>(); p->w = t.img_w; p->h = t.img_h; p->rgb = t.img_rgb8; sc.textures[i] = std::move(p); break; }
+        default: throw BuildError{FW_ERR_BAD_ARG};
+        }
+    }
+    for (uint32_t i = 0; i < d->n_textures; i++) if (d->textures[i].kind == FW_TEX_CHECKER) {
+        const fw_texture &t = d->textures[i];
+        if (t.odd < 0 || t.even < 0 || (uint32_t)t.odd >= d->n_textures || (uint32_t)t.even >= d->n_textures) throw BuildError{FW_ERR_BAD_ARG};
+        auto *c = static_cast<CheckerTexture *>(sc.textures[i].get());
+        c->odd = sc.textures[t.odd].get(); c->even = sc.textures[t.even].get();
+    }
+    auto tex = [&](int32_t ti) -> const Texture * { if (ti < 0 || (uint32_t)ti >= d->n_textures) throw BuildError{FW_ERR_BAD_ARG}; return sc.textures[ti].get(); };
+    for (uint32_t i = 0; i < d->n_materials; i++) {
+        const fw_material &m = d->materials[i];
+        switch (m.kind) {
+        case FW_MAT_LAMBERTIAN: { auto p = std::make_unique<LambertianMat>(); p->albedo = tex(m.texture); sc.materials.push_back(std::move(p)); break; }
+        case FW_MAT_METAL: { auto p = std::make_unique<MetalMat>(); p->albedo = v3(m.albedo); p->roughness = m.roughness; sc.materials.push_back(std::move(p)); break; }
+        case FW_MAT_DIELECTRIC: { auto p = std::make_unique<DielectricMat>(); p->ref_idx = m.ref_idx; sc.materials.push_back(std::move(p)); break; }
+        case FW_MAT_EMISSIVE: { auto p = std::make_unique<EmissiveMat>(); p->albedo = tex(m.texture); sc.materials.push_back(std::move(p)); break; }
+        case FW_MAT_ISOTROPIC: { auto p = std::make_unique<IsotropicMat>(); p->texture = tex(m.texture); sc.materials.push_back(std::move(p)); break; }
+        default: throw BuildError{FW_ERR_BAD_ARG};
+        }
+    }
+    const fw_environment &e = d->environment;
+    if (e.kind == FW_ENV_COLOR) { auto p = std::make_unique<ColorEnv>(); p->color = v3(e.color); sc.environment = std::move(p); }
+    else if (e.kind == FW_ENV_SKY) { auto p = std::make_unique<SkyEnv>(); p->zenith = v3(e.zenith); p->horizon = v3(e.horizon); sc.environment = std::move(p); }
+    else if (e.kind == FW_ENV_HDR) { if (!e.hdr_rgb || !e.hdr_w || !e.hdr_h) throw BuildError{FW_ERR_BAD_ARG};
+        auto p = std::make_unique<HdrEnv>(); p->w = e.hdr_w; p->h = e.hdr_h; p->rgb = e.hdr_rgb; sc.environment = std::move(p); }
+    else throw BuildError{FW_ERR_BAD_ARG};
+
+    for (uint32_t i = 0; i < d->n_objects; i++) {
+        const fw_object &o = d->objects[i];
+        auto ro = std::make_unique<RenderObjectInternal>();
+        ro->obj = make_shape(d, o.shape, sc, i, 0);
+        ro->position = v3(o.position);
+        ro->rotation_mat = rotor_into_matrix(o.rotation);
+        ro->inv_rotation_mat = rotor_into_matrix(rotor_reversed(o.rotation));
+        ro->flip_normals = o.flip_normals != 0;
+        ro->update_bounding_box();
+        sc.render_objects.push_back(std::move(ro));
+    }
+}
+
+// camera.rs:7-116
+struct Camera {
+    V3 position, horizontal, vertical, lower_left, u, v, w; float lens_radius;
+    Camera(const fw_camera_settings &s, uint32_t width, uint32_t height) {
+        float theta = s.vfov * PI_F / 180.f;
+        V3 cam_pos = v3(s.cam_pos), look_at = v3(s.look_at);
+        w = normalized(cam_pos - look_at);
+        u = normalized(cross(v3(0, 1, 0), w));
+        v = cross(w, u);
+        float half_height = std::tan(theta / 2.0f);
+        float half_width = half_height * (float)width / (float)height;
+        lower_left = cam_pos - half_width * s.focus_dist * u - half_height * s.focus_dist * v - w * s.focus_dist;
+        horizontal = 2.0f * half_width * s.focus_dist * u;
+        vertical = 2.0f * half_height * s.focus_dist * v;
+        position = cam_pos;
+        lens_radius = s.aperture / 2.f;
+    }
+    Ray ray(float s, float t, Rng &rng) const {
+        V3 rd = lens_radius * random_in_unit_disk(rng);
+        V3 offset = u * rd.x + v * rd.y;
+        return Ray{position + offset, lower_left + s * horizontal + t * vertical - position - offset};
+    }
+};
+
+// render.rs:12-33
+V3 color(const Ray &r, const SceneInternal &scene, const Hitable &root, size_t depth, Rng &rng, uint64_t *rays_per_depth) {
+    rng.segment = (uint32_t)depth;
+    rays_per_depth[depth]++;
+    Hit hit;
+    if (root.hit(r, 0.001f, 2e9f, rng, hit)) {
+        const Material &m = *scene.materials[hit.material];
+        V3 emit = m.emit(hit.u, hit.v, hit.point);
+        if (depth < 10) {
+            V3 atten; Ray sc;
+            if (m.scatter(r, hit, rng, atten, sc)) return emit + atten * color(sc, scene, root, depth + 1, rng, rays_per_depth);
+            return emit;
+        }
+        return emit;
+    }
+    return scene.environment->sample(normalized(r.d));
+}
+
+struct PixelOut { V3 linear, gamma; uint8_t rgb[3]; };
+
+// render.rs:163-196
+PixelOut render_pixel(const fw_render_params &p, const SceneInternal &scene, const Hitable &root, const Camera &cam,
+                      size_t idx, uint64_t *rays_per_depth) {
+    Rng rng;
+    rng.mode = p.rng_mode; rng.lcg = (uint64_t)idx; rng.seed32 = fold_seed(p.seed); rng.pixel = (uint32_t)idx;
+    size_t px = idx % p.width, py = p.height - (idx / p.width);          // util.rs:31-33 Coord::from_index
+    V3 total = v3(0, 0, 0);
+    for (uint32_t s = 0; s < p.samples; s++) {
+        rng.sample = s; rng.segment = 0;
+        float j[2];
+        rng.draw(P_JITTER, 0, 2, j);
+        float u = ((float)px + j[0]) / (float)p.width;
+        float v = ((float)py + j[1]) / (float)p.height;
+        Ray ray = cam.ray(u, v, rng);
+        total = total + color(ray, scene, root, 0, rng, rays_per_depth);
+    }
+    total = total / (float)p.samples;
+    PixelOut o; o.linear = total;
+    float ig = 1.f / p.gamma;
+    V3 g = v3(std::pow(total.x, ig), std::pow(total.y, ig), std::pow(total.z, ig));
+    auto clamp01 = [](float x) { if (x != x) return x; return x < 0.f ? 0.f : (x > 1.f ? 1.f : x); };
+    g = v3(clamp01(g.x), clamp01(g.y), clamp01(g.z));
+    o.gamma = g;
+    o.rgb[0] = sat_u8(g.x * 255.99f); o.rgb[1] = sat_u8(g.y * 255.99f); o.rgb[2] = sat_u8(g.z * 255.99f);   // util.rs:14-23
+    return o;
+}
+
+const char *status_str(int s) {
+    switch (s) {
+    case FW_OK: return "ok";
+    case FW_ERR_BAD_ARG: return "bad argument";
+    case FW_ERR_EMPTY_SCENE: return "No render objects added to scene!";
+    case FW_ERR_NAN_BBOX: return "Float comparison failed in BVH constructor";
+    case FW_ERR_MESH_NORMALS: return "TriangleMesh::new() -- normals.len() must equal verts.len()";
+    case FW_ERR_MESH_UVS: return "TriangleMesh::new() -- uvs.len() must equal verts.len()";
+    default: return "error";
+    }
+}
+
+} // namespace
+
+// =============================================================================
+// C entry points (prefix fwo_ = firework oracle)
+// =============================================================================
+extern "C" {
+
+const char *fwo_strerror(int s) { return status_str(s); }
+
+// Renderer::render (render.rs:109-161) on the CPU.  n_threads<=0 => hardware_concurrency.
+int fwo_render(const fw_scene_desc *desc, const fw_render_params *params, int n_threads,
+               uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats) {
+    if (!desc || !params || params->width == 0 || params->height == 0 || params->samples == 0) return FW_ERR_BAD_ARG;
+    auto t0 = std::chrono::steady_clock::now();
+    SceneInternal scene;
+    std::unique_ptr<BVHNode<ObjRef>> bvh;
+    BvhStats tl;
+    try {
+        build_scene(desc, scene);
+        if (params->use_bvh) {
+            const SceneInternal *sp = &scene;
+            bvh = build_bvh<ObjRef>([sp](size_t i) { return ObjRef{sp->render_objects[i].get()}; }, scene.render_objects.size(), tl);
+        }
+    } catch (BuildError &e) { return e.status; } catch (NanBBox &) { return FW_ERR_NAN_BBOX; } catch (std::bad_alloc &) { return FW_ERR_OOM; }
+    auto t1 = std::chrono::steady_clock::now();
+    Camera cam(params->camera, params->width, params->height);
+    const Hitable &root = params->use_bvh ? static_cast<const Hitable &>(*bvh) : static_cast<const Hitable &>(scene);
+    size_t npix = params->pixel_ids ? params->n_pixels : (size_t)params->width * params->height;
+    if (params->pixel_ids) for (size_t i = 0; i < npix; i++) if (params->pixel_ids[i] >= params->width * params->height) return FW_ERR_BAD_ARG;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    if (!params->multithreaded) n_threads = 1;
+    std::atomic<size_t> next{0};
+    const size_t CHUNK = 64;
+    std::vector<std::vector<uint64_t>> counts(n_threads, std::vector<uint64_t>(FW_MAX_SEGMENTS + 1, 0));
+    auto worker = [&](int tid) {
+        uint64_t *rpd = counts[tid].data();
+        for (;;) {
+            size_t b = next.fetch_add(CHUNK);
+            if (b >= npix) break;
+            size_t e = std::min(npix, b + CHUNK);
+            for (size_t i = b; i < e; i++) {
+                size_t idx = params->pixel_ids ? params->pixel_ids[i] : i;
+                PixelOut o = render_pixel(*params, scene, root, cam, idx, rpd);
+                if (rgb8) { rgb8[3 * i] = o.rgb[0]; rgb8[3 * i + 1] = o.rgb[1]; rgb8[3 * i + 2] = o.rgb[2]; }
+                if (gamma_rgb) { gamma_rgb[3 * i] = o.gamma.x; gamma_rgb[3 * i + 1] = o.gamma.y; gamma_rgb[3 * i + 2] = o.gamma.z; }
+                if (linear_rgb) { linear_rgb[3 * i] = o.linear.x; linear_rgb[3 * i + 1] = o.linear.y; linear_rgb[3 * i + 2] = o.linear.z; }
+            }
+        }
+    };
+    if (n_threads == 1) worker(0);
+    else { std::vector<std::thread> th; for (int t = 0; t < n_threads; t++) th.emplace_back(worker, t); for (auto &t : th) t.join(); }
+    auto t2 = std::chrono::steady_clock::now();
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        stats->samples = (uint64_t)npix * params->samples;
+        for (int t = 0; t < n_threads; t++) for (int d = 0; d < FW_MAX_SEGMENTS; d++) { stats->rays_per_depth[d] += counts[t][d]; stats->rays += counts[t][d]; }
+        stats->algorithmic_bytes = 160 * stats->rays + 24 * stats->samples;
+        stats->ms_scene = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        stats->ms_render = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        stats->tlas_nodes = tl.nodes; stats->blas_nodes = scene.blas_nodes;
+        stats->reserved = (uint32_t)n_threads;
+    }
+    return FW_OK;
+}
+
+// ---- unit-level probes for known-answer tests -------------------
+void fwo_coord_from_index(uint64_t idx, uint64_t w, uint64_t h, uint64_t out[2]) { out[0] = idx % w; out[1] = h - idx / w; }
+void fwo_color_from_vec3(const float c[3], uint8_t out[3]) { for (int i = 0; i < 3; i++) out[i] = sat_u8(c[i] * 255.99f); }
+uint32_t fwo_color_to_u32(const uint8_t c[3]) { return (uint32_t)c[0] << 16 | (uint32_t)c[1] << 8 | (uint32_t)c[2]; }
+int fwo_solve_quadratic(float a, float b, float c, float roots[2]) { return solve_quadratic(a, b, c, roots); }
+float fwo_schlick(float cosine, float ref_idx) { return schlick(cosine, ref_idx); }
+void fwo_reflect(const float v[3], const float n[3], float out[3]) { V3 r = reflect(v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2])); out[0] = r.x; out[1] = r.y; out[2] = r.z; }
+int fwo_refract(const float v[3], const float n[3], float ni_over_nt, float out[3]) {
+    V3 r; bool ok = refract(v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2]), ni_over_nt, r); if (ok) { out[0] = r.x; out[1] = r.y; out[2] = r.z; } return ok; }
+void fwo_sphere_uv(const float p[3], float out[2]) { sphere_uv(v3(p[0], p[1], p[2]), out[0], out[1]); }
+int fwo_max_component_idx(const float v[3]) { return max_component_idx(v3(v[0], v[1], v[2])); }
+float fwo_perlin_noise(const float p[3]) { return perlin_noise(v3(p[0], p[1], p[2])); }
+float fwo_turb(uint32_t depth, const float p[3]) { return turb(depth, v3(p[0], p[1], p[2])); }
+void fwo_rotor_into_matrix(const fw_rotor3 *r, float out_cols[9]) {
+    M3 m = rotor_into_matrix(*r);
+    out_cols[0] = m.c0.x; out_cols[1] = m.c0.y; out_cols[2] = m.c0.z; out_cols[3] = m.c1.x; out_cols[4] = m.c1.y; out_cols[5] = m.c1.z;
+    out_cols[6] = m.c2.x; out_cols[7] = m.c2.y; out_cols[8] = m.c2.z; }
+void fwo_rand4(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t purpose, uint32_t segment, uint32_t index, uint32_t out_u32[4], float out_f32[4]) {
+    uint32_t v[4] = {pixel, sample, ctr_dim(purpose, segment, index), fold_seed(seed)};
+    pcg4d(v);
+    for (int i = 0; i < 4; i++) { out_u32[i] = v[i]; out_f32[i] = u32_to_unit(v[i]); } }
+void fwo_lcg_stream(uint64_t seed, int n, float *out) { Rng r; r.mode = FW_RNG_LCG; r.lcg = seed; for (int i = 0; i < n; i++) out[i] = r.lcg_next(); }
+// camera.rs:74-107: out = position, lower_left, horizontal, vertical, u, v, w (7 x vec3) + lens_radius
+void fwo_camera(const fw_camera_settings *s, uint32_t w, uint32_t h, float out[22]) {
+    Camera c(*s, w, h);
+    V3 vs[7] = {c.position, c.lower_left, c.horizontal, c.vertical, c.u, c.v, c.w};
+    for (int i = 0; i < 7; i++) { out[3 * i] = vs[i].x; out[3 * i + 1] = vs[i].y; out[3 * i + 2] = vs[i].z; }
+    out[21] = c.lens_radius; }
+// environment / texture / material probes on a full scene description
+int fwo_env_sample(const fw_scene_desc *d, const float dir[3], float out[3]) {
+    SceneInternal sc; try { build_scene(d, sc); } catch (BuildError &e) { return e.status; } catch (NanBBox &) { return FW_ERR_NAN_BBOX; }
+    V3 c = sc.environment->sample(v3(dir[0], dir[1], dir[2])); out[0] = c.x; out[1] = c.y; out[2] = c.z; return FW_OK; }
+int fwo_texture_sample(const fw_scene_desc *d, int32_t tex, float u, float v, const float p[3], float out[3]) {
+    SceneInternal sc; try { build_scene(d, sc); } catch (BuildError &e) { return e.status; } catch (NanBBox &) { return FW_ERR_NAN_BBOX; }
+    if (tex < 0 || (uint32_t)tex >= d->n_textures) return FW_ERR_BAD_ARG;
+    V3 c = sc.textures[tex]->sample(u, v, v3(p[0], p[1], p[2])); out[0] = c.x; out[1] = c.y; out[2] = c.z; return FW_OK; }
+// BVH topology (bvh.rs:21-71): out = nodes, leaves, double_leaves, branches, depth for TLAS; blas node total
+int fwo_bvh_stats(const fw_scene_desc *d, uint32_t out[6]) {
+    SceneInternal sc; BvhStats tl;
+    try { build_scene(d, sc); const SceneInternal *sp = &sc;
+        auto b = build_bvh<ObjRef>([sp](size_t i) { return ObjRef{sp->render_objects[i].get()}; }, sc.render_objects.size(), tl);
+    } catch (BuildError &e) { return e.status; } catch (NanBBox &) { return FW_ERR_NAN_BBOX; }
+    out[0] = tl.nodes; out[1] = tl.leaves; out[2] = tl.double_leaves; out[3] = tl.branches; out[4] = tl.depth; out[5] = sc.blas_nodes;
+    return FW_OK; }
+int fwo_mesh_bvh_stats(const fw_scene_desc *d, uint32_t object, uint32_t out[5]) {
+    SceneInternal sc; try { build_scene(d, sc); } catch (BuildError &e) { return e.status; } catch (NanBBox &) { return FW_ERR_NAN_BBOX; }
+    if (object >= sc.render_objects.size()) return FW_ERR_BAD_ARG;
+    auto *mh = dynamic_cast<MeshHitable *>(sc.render_objects[object]->obj.get());
+    if (!mh) return FW_ERR_BAD_ARG;
+    out[0] = mh->stats.nodes; out[1] = mh->stats.leaves; out[2] = mh->stats.double_leaves; out[3] = mh->stats.branches; out[4] = mh->stats.depth;
+    return FW_OK; }
+// world AABB of each object (scene.rs:177-212): out = n_objects x 6 floats
+int fwo_object_aabbs(const fw_scene_desc *d, float *out) {
+    SceneInternal sc; try { build_scene(d, sc); } catch (BuildError &e) { return e.status; } catch (NanBBox &) { return FW_ERR_NAN_BBOX; }
+    for (size_t i = 0; i < sc.render_objects.size(); i++) { const AABB &a = sc.render_objects[i]->aabb;
+        out[6 * i] = a.mn.x; out[6 * i + 1] = a.mn.y; out[6 * i + 2] = a.mn.z; out[6 * i + 3] = a.mx.x; out[6 * i + 4] = a.mx.y; out[6 * i + 5] = a.mx.z; }
+    return FW_OK; }
+// One root.hit() (render.rs:19) for a table of rays: per ray out = hit flag, t, point, normal, material, u, v (10 floats).
+// CTR draws use (seed, pixel=ray index, sample=0, segment=0).
+int fwo_trace(const fw_scene_desc *d, int use_bvh, uint64_t seed, uint32_t n_rays, const float *rays /*6 per ray*/, float *out /*10 per ray*/) {
+    SceneInternal sc; std::unique_ptr<BVHNode<ObjRef>> bvh; BvhStats tl;
+    try { build_scene(d, sc);
+        if (use_bvh) { const SceneInternal *sp = &sc; bvh = build_bvh<ObjRef>([sp](size_t i) { return ObjRef{sp->render_objects[i].get()}; }, sc.render_objects.size(), tl); }
+    } catch (BuildError &e) { return e.status; } catch (NanBBox &) { return FW_ERR_NAN_BBOX; }
+    const Hitable &root = use_bvh ? static_cast<const Hitable &>(*bvh) : static_cast<const Hitable &>(sc);
+    for (uint32_t i = 0; i < n_rays; i++) {
+        Rng rng; rng.mode = FW_RNG_CTR; rng.seed32 = fold_seed(seed); rng.pixel = i; rng.sample = 0; rng.segment = 0;
+        Ray r{v3(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]), v3(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5])};
+        Hit h; float *o = out + 10 * i;
+        if (root.hit(r, 0.001f, 2e9f, rng, h)) { o[0] = 1; o[1] = h.t; o[2] = h.point.x; o[3] = h.point.y; o[4] = h.point.z; o[5] = h.normal.x; o[6] = h.normal.y; o[7] = h.normal.z;
+            o[8] = (float)h.material; o[9] = h.u; /* v dropped to keep 10 */ }
+        else { for (int k = 0; k < 10; k++) o[k] = 0; }
+    }
+    return FW_OK; }
+
+} // extern "C"

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Regenerates the DATA fixtures that come from the reference's data files (not its source code).
+
+  scenes/suzanne_mesh.npz   <- /root/reference/scenes/suzanne.yml  (TriangleMesh verts/indices =
+                               tobj 1.0's output for suzanne.obj; 1966 verts, 968 triangles)
+  scenes/earthmap.jpg       <- /root/reference/earthmap.jpg        (ImageTexture of part2_all)
+  tests/golden/reference_png_stats.json <- block means of the reference's committed renders
+                               (cornell_box.png, suzanne.png, volume.png, ...): the only
+                               reference-produced outputs that exist
+  tests/golden/reference_yaml_pins.json <- rotor values found in scenes/*.yml
+
+Run in the build container only (/root/reference does not exist on the GPU box)."""
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+import yaml
+from PIL import Image
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    with open(f"{REF}/scenes/suzanne.yml") as f:
+        y = yaml.safe_load(f)
+    mesh = y["render_objects"][0]["obj"]
+    assert mesh["object_type"] == "TriangleMesh"
+    verts = np.array([[v["x"], v["y"], v["z"]] for v in mesh["verts"]], np.float32)
+    idx = np.array(mesh["indicies"], np.uint32)
+    assert mesh["normals"] is None and mesh["uvs"] is None
+    np.savez_compressed(f"{ROOT}/scenes/suzanne_mesh.npz", verts=verts, indicies=idx)
+    print("suzanne:", verts.shape, idx.shape)
+    shutil.copyfile(f"{REF}/earthmap.jpg", f"{ROOT}/scenes/earthmap.jpg")
+
+    def blocks(name, rows, cols):
+        im = np.asarray(Image.open(f"{REF}/{name}").convert("RGB"), np.float64)
+        h, w, _ = im.shape
+        bh, bw = h // rows, w // cols
+        out = [[[round(float(x), 2) for x in im[r * bh:(r + 1) * bh, c * bw:(c + 1) * bw].reshape(-1, 3).mean(0)]
+                for c in range(cols)] for r in range(rows)]
+        return dict(width=w, height=h, rows=rows, cols=cols, block_means=out,
+                    mean=[round(float(x), 2) for x in im.reshape(-1, 3).mean(0)])
+
+    stats = {
+        "cornell_box.png": blocks("cornell_box.png", 6, 6),
+        "suzanne.png": blocks("suzanne.png", 4, 6),
+        "volume.png": blocks("volume.png", 4, 6),
+        "random_spheres.png": blocks("random_spheres.png", 4, 6),
+        "part2_final.png": blocks("part2_final.png", 4, 3),
+    }
+    with open(f"{ROOT}/tests/golden/reference_png_stats.json", "w") as f:
+        json.dump(stats, f, indent=1)
+
+    pins = []
+    for sc in ("conics.yml", "suzanne.yml", "teapot.yml"):
+        with open(f"{REF}/scenes/{sc}") as f:
+            yy = yaml.safe_load(f)
+        for i, ro in enumerate(yy["render_objects"]):
+            r = ro["rotation"]
+            if r["s"] != 1.0:
+                pins.append(dict(scene=sc, object=i, s=r["s"], xy=r["bv"]["xy"], xz=r["bv"]["xz"], yz=r["bv"]["yz"]))
+    with open(f"{ROOT}/tests/golden/reference_yaml_pins.json", "w") as f:
+        json.dump(pins, f, indent=1)
+    print(len(pins), "rotor pins")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
