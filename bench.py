@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's metric on BASELINE.json's config.
+
+metric : Mrays/s (+ Msamples/s and frame time) of cornell_box 512x512 @1024spp  (configs[1])
+step   : one full frame through the HIP wavefront path (scene already resident in HBM), tiles
+         sharded over the ranks, + the single gather of finished tiles to rank 0
+N>1    : launched by torch.distributed.run, one rank per GPU, RCCL (backend "nccl")
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     — dominant kernel's algorithmic HBM bytes / its HIP-event time vs the 8 TB/s peak
+  cpu_baseline — the CPU oracle (a C++ restatement of the reference's rayon loop; the Rust binary cannot
+                 be built in this image) timed on this host's cores on a bounded sample of the same scene
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C2_cornell_box")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--paths-per-batch", type=int, default=0)
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events (no roofline object)")
+    ap.add_argument("--cpu-spp", type=int, default=96, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from firework_amd import scenes
+    from firework_amd.tiles import TiledRenderer
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    scene, renderer = scenes.config(args.config, args.width, args.height, args.spp)
+    if args.paths_per_batch:
+        renderer.paths_per_batch(args.paths_per_batch)
+    if not args.no_kernel_timing:
+        renderer.time_kernels(True)
+    s = renderer.settings
+    tr = TiledRenderer(scene, renderer, rank, world, local_rank, dist=dist if world > 1 else None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.render_frame()
+    barrier()
+    t0 = time.perf_counter()
+    acc = {"rays": 0, "samples": 0, "ms_render": 0.0, "ms_extend": 0.0, "ms_shade": 0.0, "ms_raygen": 0.0,
+           "ms_accumulate": 0.0, "n_extend_launches": 0}
+    for _ in range(args.steps):
+        tr.render_frame()
+        for k in acc:
+            acc[k] += tr.last_stats[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # max over ranks of the elapsed time; sums over ranks of the work counters
+    vec = torch.tensor([elapsed, acc["rays"], acc["samples"], acc["ms_extend"], acc["ms_shade"], acc["ms_render"]],
+                       dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = vec.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+    total_rays, total_samples = float(vec[1]), float(vec[2])
+
+    if rank == 0:
+        frame = tr.frame.cpu().numpy()
+        assert frame.shape == (s["width"] * s["height"], 3) and frame.any()
+        ms_step = elapsed * 1e3 / args.steps
+        out = {
+            "metric": "Mrays/s, cornell_box 512x512 @1024spp (whole frame incl. tile gather)" if args.config == "C2_cornell_box" and not (args.width or args.spp) else f"Mrays/s, {args.config}",
+            "value": total_rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config} {s['width']}x{s['height']} @{s['samples']}spp", "use_bvh": bool(s["use_bvh"]),
+                       "tiles": "32x32 round-robin over ranks", "collective": "one gather of u8 tiles to rank 0" if world > 1 else "none",
+                       "rng": "counter (pcg4d) keyed by (seed,pixel,sample,dimension)", "seed": s["seed"]},
+            "msamples_per_s": total_samples / elapsed / 1e6,
+            "frame_time_ms": ms_step,
+            "rays_per_sample": total_rays / max(1.0, total_samples),
+        }
+        if not args.no_kernel_timing:
+            # rank-0 kernel classes (every rank runs the same kernels on 1/N of the pixels)
+            rays0 = acc["rays"]
+            ext_bytes = 40.0 * rays0          # extend: reads ray 24 B, writes hit 16 B      
+            shd_bytes = 120.0 * rays0         # shade: ray 24 + hit 16 + state 24 in, ray 24 + state 24 out, 8 queue
+            ext_s, shd_s = acc["ms_extend"] / 1e3, acc["ms_shade"] / 1e3
+            dom = "k_extend" if ext_s >= shd_s else "k_shade"
+            b, t = (ext_bytes, ext_s) if dom == "k_extend" else (shd_bytes, shd_s)
+            ach = b / t / 1e9 if t > 0 else 0.0
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                               "avg_launch_us": t * 1e6 / max(1, acc["n_extend_launches"]),
+                               "bytes_per_ray": 40 if dom == "k_extend" else 120}
+            frame_bytes = 160.0 * rays0 + 24.0 * acc["samples"]
+            out["roofline_frame"] = {"achieved": frame_bytes / (acc["ms_render"] / 1e3) / 1e9, "unit": "GB/s",
+                                     "frac": frame_bytes / (acc["ms_render"] / 1e3) / 1e9 / HBM_PEAK_GBS,
+                                     "formula": "160*rays + 24*samples over device time"}
+            out["kernel_ms_per_step"] = {k: acc[k] / args.steps for k in ("ms_render", "ms_raygen", "ms_extend", "ms_shade", "ms_accumulate")}
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import oracle_binding as ob       # CPU oracle: the checker, timed as the reported baseline
+            from firework_amd._abi import FW_RNG_LCG
+            cscene, cr = scenes.config(args.config, args.width, args.height, args.cpu_spp)
+            cores = os.cpu_count() or 1
+            c0 = time.perf_counter()
+            cres = ob.render(cscene, cr, rng_mode=FW_RNG_LCG, n_threads=cores)   # reference semantics: per-pixel sequential LCG
+            cdt = time.perf_counter() - c0
+            out["cpu_baseline"] = {"value": cres.stats["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                                   "msamples_per_s": cres.stats["samples"] / cdt / 1e6,
+                                   "sample": f"{args.config} {cr.settings['width']}x{cr.settings['height']} @{args.cpu_spp}spp "
+                                             f"({cres.stats['samples']} samples, {cdt:.1f} s; cost is linear in spp)"}
+        print(json.dumps(out))
+    tr.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

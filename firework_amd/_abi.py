@@ -24,6 +24,7 @@ FW_MAT_LAMBERTIAN, FW_MAT_METAL, FW_MAT_DIELECTRIC, FW_MAT_EMISSIVE, FW_MAT_ISOT
  FW_SHAPE_TRIANGLE_MESH, FW_SHAPE_CONSTANT_MEDIUM) = range(7)
 FW_ENV_COLOR, FW_ENV_SKY, FW_ENV_HDR = range(3)
 FW_RNG_CTR, FW_RNG_LCG = 0, 1
+FW_FLAG_TIME_KERNELS = 1
 
 f32, i32, u32, u64 = C.c_float, C.c_int32, C.c_uint32, C.c_uint64
 
@@ -78,7 +79,7 @@ class fw_camera_settings(C.Structure):
 class fw_render_params(C.Structure):
     _fields_ = [("width", u32), ("height", u32), ("samples", u32), ("gamma", f32), ("use_bvh", i32),
                 ("multithreaded", i32), ("camera", fw_camera_settings), ("seed", u64), ("rng_mode", i32),
-                ("pixel_ids", C.POINTER(u32)), ("n_pixels", u32), ("paths_per_batch", u32),
+                ("pixel_ids", C.POINTER(u32)), ("n_pixels", u32), ("paths_per_batch", u32), ("flags", u32),
                 ("outputs_on_device", i32), ("stream", C.c_void_p)]
 
 

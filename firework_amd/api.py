@@ -659,7 +659,7 @@ class Renderer:
     def __init__(self):
         # Default (render.rs:199-218)
         self.settings = dict(width=1920, height=1080, samples=128, multithreaded=True, use_bvh=False, gamma=2.2,
-                             seed=0, paths_per_batch=0)
+                             seed=0, paths_per_batch=0, flags=0)
         self._camera = CameraSettings()
 
     @staticmethod
@@ -703,6 +703,11 @@ class Renderer:
         self.settings["paths_per_batch"] = int(n)
         return self
 
+    def time_kernels(self, on=True):
+        self.settings["flags"] = (self.settings["flags"] | A.FW_FLAG_TIME_KERNELS) if on else (
+            self.settings["flags"] & ~A.FW_FLAG_TIME_KERNELS)
+        return self
+
     def to_params(self, pixel_ids: Optional[np.ndarray] = None, rng_mode: int = A.FW_RNG_CTR) -> A.fw_render_params:
         s = self.settings
         p = A.fw_render_params()
@@ -714,6 +719,7 @@ class Renderer:
         p.seed = s["seed"]
         p.rng_mode = rng_mode
         p.paths_per_batch = s["paths_per_batch"]
+        p.flags = s["flags"]
         if pixel_ids is not None:
             p.pixel_ids = pixel_ids.ctypes.data_as(C.POINTER(C.c_uint32))
             p.n_pixels = int(pixel_ids.shape[0])

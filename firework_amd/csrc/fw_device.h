@@ -1,0 +1,115 @@
+// fw_device.h — HBM data layout shared by the host runtime (fw_runtime.cpp) and the kernels
+// (fw_kernels.hip).  See DESIGN.md §"Data layout in HBM".
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fw {
+
+// ---- object record: 6 x float4 = 96 B, 16-B aligned (one RenderObjectInternal, scene.rs:165-174,
+//      with its shape inlined).  Linear scenes read it with a wave-uniform index (scalar loads),
+//      TLAS leaves with a per-lane index (float4 vector loads).
+//   q0 = (R00 R01 R02 pos.x)   rows of rotation_mat, translation in .w
+//   q1 = (R10 R11 R12 pos.y)   (inv_rotation_mat is exactly the transpose: scene.rs:285)
+//   q2 = (R20 R21 R22 pos.z)
+//   q3, q4 = shape parameters (below)
+//   q5 = (bits: kind | flags<<8 | inner_kind<<24, bits: material, bits: aux0, bits: aux1)
+constexpr int OBJ_Q = 6;
+
+enum : uint32_t {
+    OF_ROTATED = 1u << 0,      // 0.5*(trace R - 1) < 0.999  (scene.rs:187,242)
+    OF_FLIP = 1u << 1,         // RenderObject.flip_normals
+    OF_RECT_FLIP = 1u << 2,    // AARect.flip_normal
+    OF_MESH_NORMALS = 1u << 3, // TriangleMesh.normals is Some
+    OF_MESH_ATTR = 1u << 4,    // the per-triangle attribute array (normals and/or v coordinates) is valid
+};
+// shape parameters:
+//   sphere : q3.x = radius
+//   rect   : q3 = (a_min a_max b_min b_max)  q4.x = k
+//   rect3d : q3 = (pos.x pos.y pos.z size.x) q4 = (size.y size.z - -)
+//   mesh   : aux0 = BLAS root node index, aux1 = first triangle index
+//   medium : inner shape parameters in q3/q4 as above, q4.w = density, material = the Isotropic
+//            material, aux0/aux1 as for a mesh when the inner shape is one
+
+// ---- BVH node: 2 x float4 = 32 B.  DFS order: the left child of node i is i+1.
+//   lo = (min.xyz, bits A)   hi = (max.xyz, bits B)
+//   A>>30 == 0: Branch      right child = A & 0x3fffffff
+//   A>>30 == 1: Leaf        item = A & 0x3fffffff
+//   A>>30 == 2: DoubleLeaf  items = A & 0x3fffffff, B
+constexpr uint32_t NODE_LEAF = 1u, NODE_DOUBLE = 2u, NODE_MASK = 0x3fffffffu;
+
+// ---- triangle: 3 x float4 = 48 B: (p0.xyz u0) (p1.xyz u1) (p2.xyz u2), vertices pre-gathered through
+//      the index buffer.  Meshes with vertex normals and/or uvs add an attribute array of 3 x float4:
+//      (n0.xyz v0) (n1.xyz v1) (n2.xyz v2).  Without uvs the defaults (0,0),(1,0),(0,1) of mesh.rs:99-109
+//      are u = (0,1,0) in the .w lanes and v = (0,0,1) as constants.
+// ---- material: 2 x float4: (bits kind, bits texture, roughness, ref_idx) (albedo.rgb, -)
+// ---- texture : 2 x float4: (bits kind, scale, bits depth, bits odd) then by kind:
+//        constant (color.rgb -) | checker (bits even - - -) | image (bits byte offset, bits w, bits h, -)
+
+struct DEnv {
+    int32_t kind;
+    float color[3];
+    float zenith[3];
+    float horizon[3];
+    const float *hdr;      // equirect f32 RGB in HBM
+    uint32_t hdr_w, hdr_h;
+};
+
+struct DScene {
+    const float4 *obj;
+    const float4 *tlas;
+    const float4 *blas;
+    const float4 *tri;
+    const float4 *tri_nrm;   // same indexing as tri; valid only for meshes with OF_MESH_NORMALS
+    const float4 *mat;
+    const float4 *tex;
+    const uint8_t *images;
+    uint32_t n_objects;
+    uint32_t has_medium;
+    DEnv env;
+};
+
+struct DCamera {   // camera.rs:7-16
+    float position[3], horizontal[3], vertical[3], lower_left[3], u[3], v[3];
+    float lens_radius;
+};
+
+struct DFrame {
+    uint32_t width, height;
+    uint32_t n_pixels;            // pixels this call renders
+    const uint32_t *pixel_ids;    // device copy of fw_render_params.pixel_ids, or nullptr
+    uint32_t seed32;
+    uint32_t sample0;             // first sample index of this batch
+    uint32_t spp_batch;           // samples per pixel in this batch
+};
+
+// ---- wavefront path state, SoA over path slots (DESIGN.md §"Path state")
+struct DPaths {
+    float4 *ray_a;   // (o.x o.y o.z d.x)
+    float2 *ray_b;   // (d.y d.z)
+    float4 *state;   // (beta.r beta.g beta.b, bits path_id)
+};
+
+constexpr uint32_t MISS = 0xffffffffu;
+constexpr int MAX_SEGMENTS = 11;
+constexpr int COUNT_STRIDE = 16;  // u32 counters per batch: [0..10] queue sizes, [11] spare
+
+// launch wrappers (fw_kernels.hip)
+struct LaunchCfg {
+    hipStream_t stream;
+    int blocks_extend, blocks_shade, blocks_other;
+    int tlas_depth, blas_depth;   // LDS traversal-stack levels needed
+};
+
+void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, uint32_t *counts, uint32_t n_paths);
+void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float4 *hits, const uint32_t *counts,
+                   int segment, bool use_bvh);
+void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, const float4 *hits,
+                  float4 *sample_rad, uint32_t *counts, int segment);
+void launch_accumulate(const LaunchCfg &, const DFrame &, const float4 *sample_rad, float4 *accum);
+void launch_resolve(const LaunchCfg &, const DFrame &, const float4 *accum, uint32_t total_spp, float gamma,
+                    uint8_t *rgb8, float *gamma_rgb, float *linear_rgb);
+
+constexpr int BLOCK = 256;
+
+} // namespace fw

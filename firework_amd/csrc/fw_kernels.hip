@@ -1,0 +1,737 @@
+// fw_kernels.hip — the wavefront path tracer's kernels for gfx950 (MI355X, CDNA4).
+//
+// Replaces the body of the reference's `Renderer::render()` pixel loop (src/render.rs:127-196):
+//
+//   k_raygen      render_pixel's loop head + Camera::ray          render.rs:172-180, camera.rs:109-116
+//   k_extend      root.hit(): linear scene / TLAS + per-object     scene.rs:137-149,235-266, bvh.rs:115-151,
+//                 transform + primitive intersectors + mesh BLAS   objects/*.rs
+//   k_shade       Material::emit/scatter, Texture::sample,         render.rs:19-31, material.rs, texture.rs,
+//                 Environment::sample, + stream compaction         environment.rs
+//   k_accumulate  `total_color += color(..)` in sample order      render.rs:181
+//   k_resolve     /spp, powf(1/gamma), clamp, Color::from          render.rs:184-190, util.rs:14-23
+//
+// One lane = one path.  Path state lives in HBM as SoA arrays and is compacted every segment with
+// wave ballots + one atomic per workgroup; all paths of a queue are at the same depth, so the depth
+// is a kernel argument, not state.  Every random draw is a pure function of
+// (seed, pixel, sample, dimension), so the image does not depend on scheduling.
+//
+// Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE-exact and written in the same
+// association as the reference's expressions, so hit/miss decisions follow the CPU oracle bit for
+// bit; only libm-class functions (sin, atan2, asin, log10, pow) differ by ulps.
+#include "fw_device.h"
+
+namespace fw {
+
+// ------------------------------------------------------------------------------------------------
+// small vector type (ultraviolet::Vec3 semantics: dot/cross/mag_sq via fma, `/` component-wise)
+// ------------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return {fmaf(a.y, b.z, -a.z * b.y), fmaf(a.z, b.x, -a.x * b.z), fmaf(a.x, b.y, -a.y * b.x)};
+}
+__device__ __forceinline__ float mag_sq(V3 a) { return dot(a, a); }
+__device__ __forceinline__ float mag(V3 a) { return sqrtf(mag_sq(a)); }
+__device__ __forceinline__ V3 normalized(V3 a) { float m = mag(a); return {a.x / m, a.y / m, a.z / m}; }
+__device__ __forceinline__ float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+__device__ __forceinline__ V3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
+
+struct Ray { V3 o, d; };
+__device__ __forceinline__ V3 ray_point(const Ray &r, float t) { return r.o + t * r.d; }
+
+// ------------------------------------------------------------------------------------------------
+// counter RNG: pcg4d(pixel, sample, dimension, seed32) -> 4 x u32; float = (u >> 8) * 2^-24
+// ------------------------------------------------------------------------------------------------
+enum : uint32_t { P_JITTER = 0, P_LENS = 1, P_SCATTER = 2, P_FRESNEL = 3, P_VOLUME = 4 };
+
+struct RngKey { uint32_t pixel, sample, seed32; };
+
+__device__ __forceinline__ uint4 pcg4d(uint4 v) {
+    v.x = v.x * 1664525u + 1013904223u; v.y = v.y * 1664525u + 1013904223u;
+    v.z = v.z * 1664525u + 1013904223u; v.w = v.w * 1664525u + 1013904223u;
+    v.x += v.y * v.w; v.y += v.z * v.x; v.z += v.x * v.y; v.w += v.y * v.z;
+    v.x ^= v.x >> 16; v.y ^= v.y >> 16; v.z ^= v.z >> 16; v.w ^= v.w >> 16;
+    v.x += v.y * v.w; v.y += v.z * v.x; v.z += v.x * v.y; v.w += v.y * v.z;
+    return v;
+}
+__device__ __forceinline__ float u2f(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ uint4 draw(const RngKey &k, uint32_t purpose, uint32_t segment, uint32_t index) {
+    return pcg4d(make_uint4(k.pixel, k.sample, purpose | (segment << 3) | (index << 7), k.seed32));
+}
+
+constexpr uint32_t MAX_REJECT = 1024;   // exit condition for the rejection loops (P(miss 1024x) ~ 1e-330)
+
+// util.rs:36-43
+__device__ __forceinline__ V3 random_in_unit_sphere(const RngKey &k, uint32_t segment) {
+    V3 p = mk(0.f, 0.f, 0.f);
+    for (uint32_t attempt = 0; attempt < MAX_REJECT; attempt++) {
+        uint4 u = draw(k, P_SCATTER, segment, attempt);
+        p = 2.0f * mk(u2f(u.x), u2f(u.y), u2f(u.z)) - mk(1.f, 1.f, 1.f);
+        if (mag_sq(p) < 1.0f) break;
+    }
+    return p;
+}
+// util.rs:45-52
+__device__ __forceinline__ V3 random_in_unit_disk(const RngKey &k) {
+    V3 p = mk(0.f, 0.f, 0.f);
+    for (uint32_t attempt = 0; attempt < MAX_REJECT; attempt++) {
+        uint4 u = draw(k, P_LENS, 0, attempt);
+        p = 2.0f * mk(u2f(u.x), u2f(u.y), 0.f) - mk(1.f, 1.f, 0.f);
+        if (dot(p, p) < 1.0f) break;
+    }
+    return p;
+}
+
+// path_id -> (pixel index as in render.rs:127, sample index)
+__device__ __forceinline__ RngKey key_of(const DFrame &f, uint32_t path_id) {
+    uint32_t s_local = path_id / f.n_pixels;
+    uint32_t p_local = path_id - s_local * f.n_pixels;
+    RngKey k;
+    k.pixel = f.pixel_ids ? f.pixel_ids[p_local] : p_local;
+    k.sample = f.sample0 + s_local;
+    k.seed32 = f.seed32;
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1  ray generation
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_raygen(DCamera cam, DFrame f, DPaths out, uint32_t *counts, uint32_t n_paths) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n_paths;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_paths; i += gridDim.x * BLOCK) {
+        RngKey k = key_of(f, i);
+        uint32_t px = k.pixel % f.width;                 // util.rs:31-33 Coord::from_index
+        uint32_t py = f.height - k.pixel / f.width;
+        uint4 j = draw(k, P_JITTER, 0, 0);
+        float u = ((float)px + u2f(j.x)) / (float)f.width;      // render.rs:178
+        float v = ((float)py + u2f(j.y)) / (float)f.height;     // render.rs:179
+        // camera.rs:109-116 — the disk sample is drawn even when the aperture is 0
+        V3 rd = cam.lens_radius * random_in_unit_disk(k);
+        V3 cu = ld3(cam.u), cv = ld3(cam.v), pos = ld3(cam.position);
+        V3 offset = cu * rd.x + cv * rd.y;
+        V3 o = pos + offset;
+        V3 d = ld3(cam.lower_left) + u * ld3(cam.horizontal) + v * ld3(cam.vertical) - pos - offset;
+        out.ray_a[i] = make_float4(o.x, o.y, o.z, d.x);
+        out.ray_b[i] = make_float2(d.y, d.z);
+        out.state[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// object record access + world<->object transform (scene.rs:235-266)
+// ------------------------------------------------------------------------------------------------
+struct Obj { float4 q0, q1, q2, q3, q4; uint32_t kf, material, aux0, aux1; };
+
+__device__ __forceinline__ Obj load_obj(const float4 *__restrict__ objs, uint32_t j) {
+    const float4 *p = objs + (size_t)j * OBJ_Q;
+    Obj o;
+    o.q0 = p[0]; o.q1 = p[1]; o.q2 = p[2]; o.q3 = p[3]; o.q4 = p[4];
+    float4 q5 = p[5];
+    o.kf = __float_as_uint(q5.x); o.material = __float_as_uint(q5.y);
+    o.aux0 = __float_as_uint(q5.z); o.aux1 = __float_as_uint(q5.w);
+    return o;
+}
+__device__ __forceinline__ uint32_t obj_kind(const Obj &o) { return o.kf & 0xffu; }
+__device__ __forceinline__ uint32_t obj_flags(const Obj &o) { return (o.kf >> 8) & 0xffffu; }
+__device__ __forceinline__ uint32_t obj_inner(const Obj &o) { return o.kf >> 24; }
+
+// inv_rotation_mat * v  (columns of R^T are the rows of R; Mat3*Vec3 = c0*x + c1*y + c2*z, plain mul/add)
+__device__ __forceinline__ V3 rot_inv(const Obj &o, V3 v) {
+    return {o.q0.x * v.x + o.q1.x * v.y + o.q2.x * v.z,
+            o.q0.y * v.x + o.q1.y * v.y + o.q2.y * v.z,
+            o.q0.z * v.x + o.q1.z * v.y + o.q2.z * v.z};
+}
+// rotation_mat * v
+__device__ __forceinline__ V3 rot_fwd(const Obj &o, V3 v) {
+    return {o.q0.x * v.x + o.q0.y * v.y + o.q0.z * v.z,
+            o.q1.x * v.x + o.q1.y * v.y + o.q1.z * v.z,
+            o.q2.x * v.x + o.q2.y * v.y + o.q2.z * v.z};
+}
+__device__ __forceinline__ Ray to_object_space(const Obj &o, const Ray &r) {
+    V3 pos = mk(o.q0.w, o.q1.w, o.q2.w);
+    if (obj_flags(o) & OF_ROTATED) return Ray{rot_inv(o, r.o - pos), rot_inv(o, r.d)};
+    return Ray{r.o - pos, r.d};
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3  primitive intersectors (object space).  Each returns t (and a primitive id where one exists).
+// ------------------------------------------------------------------------------------------------
+// objects/mod.rs:19-31 + objects/sphere.rs:31-60
+__device__ __forceinline__ bool hit_sphere(float radius, const Ray &r, float tmin, float tmax, float &t_out) {
+    float a = dot(r.d, r.d);
+    float b = 2.f * dot(r.o, r.d);
+    float c = dot(r.o, r.o) - radius * radius;
+    float disc = b * b - 4.f * a * c;
+    if (disc < 0.f) return false;
+    float t1, t2; bool two;
+    if (disc == 0.f) { t1 = -b / (2.f * a); t2 = 0.f; two = false; }
+    else { float sq = sqrtf(disc); t1 = (-b - sq) / (2.f * a); t2 = (-b + sq) / (2.f * a); two = true; }
+    if (t1 < tmax && t1 > tmin) { t_out = t1; return true; }
+    if (two && t2 < tmax && t2 > tmin) { t_out = t2; return true; }
+    return false;
+}
+
+// objects/rect.rs:47-73.  AX: 0 = XY (plane axis z), 1 = XZ (plane axis y), 2 = YZ (plane axis x)
+template <int AX>
+__device__ __forceinline__ bool hit_rect(float a_min, float a_max, float b_min, float b_max, float k, const Ray &r,
+                                         float tmin, float tmax, float &t_out) {
+    constexpr int A1 = (AX == 2) ? 1 : 0, A2 = (AX == 0) ? 1 : 2, OT = (AX == 0) ? 2 : (AX == 1 ? 1 : 0);
+    float t = (k - comp(r.o, OT)) / comp(r.d, OT);
+    if (t < tmin || t > tmax) return false;
+    V3 p = ray_point(r, t);
+    float pa = comp(p, A1), pb = comp(p, A2);
+    if (pa < a_min || pa > a_max || pb < b_min || pb > b_max) return false;
+    t_out = t;
+    return true;
+}
+__device__ __forceinline__ bool hit_rect_kind(uint32_t kind, float4 q3, float k, const Ray &r, float tmin, float tmax, float &t) {
+    if (kind == 1) return hit_rect<0>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
+    if (kind == 2) return hit_rect<1>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
+    return hit_rect<2>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
+}
+
+// objects/rect3d.rs:18-100 — faces +z, -z, +y, -y, +x, -x; linear closest with narrowing, later wins ties
+__device__ __forceinline__ bool hit_rect3d(float4 q3, float4 q4, const Ray &r, float tmin, float tmax, float &t_out, uint32_t &face) {
+    float px = q3.x, py = q3.y, pz = q3.z, sx = q3.w, sy = q4.x, sz = q4.y;
+    bool any = false; float closest = tmax, t;
+    if (hit_rect<0>(px, px + sx, py, py + sy, pz + sz, r, tmin, closest, t)) { closest = t; face = 0; any = true; }
+    if (hit_rect<0>(px, px + sx, py, py + sy, pz, r, tmin, closest, t)) { closest = t; face = 1; any = true; }
+    if (hit_rect<1>(px, px + sx, pz, pz + sz, py + sy, r, tmin, closest, t)) { closest = t; face = 2; any = true; }
+    if (hit_rect<1>(px, px + sx, pz, pz + sz, py, r, tmin, closest, t)) { closest = t; face = 3; any = true; }
+    if (hit_rect<2>(py, py + sy, pz, pz + sz, px + sx, r, tmin, closest, t)) { closest = t; face = 4; any = true; }
+    if (hit_rect<2>(py, py + sy, pz, pz + sz, px, r, tmin, closest, t)) { closest = t; face = 5; any = true; }
+    t_out = closest;
+    return any;
+}
+
+// util.rs:104-118 — SIGNED comparison
+__device__ __forceinline__ int max_component_idx(V3 v) {
+    if (v.x > v.y) return (v.z > v.x) ? 2 : 0;
+    return (v.z > v.y) ? 2 : 1;
+}
+
+// objects/mesh.rs:139-219.  Returns t and the barycentrics.
+__device__ __forceinline__ bool hit_triangle(V3 p0, V3 p1, V3 p2, const Ray &r, float tmin, float tmax,
+                                             float &t_out, float &b0, float &b1, float &b2) {
+    V3 p0t = p0 - r.o, p1t = p1 - r.o, p2t = p2 - r.o;
+    int kz = max_component_idx(r.d);
+    int kx = (kz + 1) % 3;
+    int ky = (kx + 1) % 3;
+    V3 d = mk(comp(r.d, kx), comp(r.d, ky), comp(r.d, kz));
+    p0t = mk(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
+    p1t = mk(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
+    p2t = mk(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
+    float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.f / d.z;
+    p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
+    p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
+    p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+    float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
+    float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
+    float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
+    if ((e0 < 0.f || e1 < 0.f || e2 < 0.f) && (e0 > 0.f || e1 > 0.f || e2 > 0.f)) return false;
+    float det = e0 + e1 + e2;
+    if (det == 0.f) return false;
+    p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+    float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
+    if (det < 0.f && (t_scaled >= tmin * det || t_scaled < tmax * det)) return false;
+    else if (det > 0.f && (t_scaled <= tmin * det || t_scaled > tmax * det)) return false;
+    float inv_det = 1.f / det;
+    b0 = e0 * inv_det; b1 = e1 * inv_det; b2 = e2 * inv_det;
+    t_out = t_scaled * inv_det;
+    return true;
+}
+
+// aabb.rs:30-50 with the reciprocal directions hoisted (1/d is the same value every call)
+__device__ __forceinline__ bool hit_aabb(float4 lo, float4 hi, V3 o, V3 inv, float tmin, float tmax) {
+    float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
+    if (inv.x < 0.f) { float s = t0; t0 = t1; t1 = s; }
+    tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1);
+    if (!(tmax > tmin)) return false;
+    t0 = (lo.y - o.y) * inv.y; t1 = (hi.y - o.y) * inv.y;
+    if (inv.y < 0.f) { float s = t0; t0 = t1; t1 = s; }
+    tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1);
+    if (!(tmax > tmin)) return false;
+    t0 = (lo.z - o.z) * inv.z; t1 = (hi.z - o.z) * inv.z;
+    if (inv.z < 0.f) { float s = t0; t0 = t1; t1 = s; }
+    tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1);
+    return tmax > tmin;
+}
+
+// Per-lane traversal stack in LDS, laid out [level][lane] so a push/pop by the whole wave touches
+// 64 consecutive dwords (conflict-free).  `base` = first level this traversal may use.
+struct LdsStack {
+    uint32_t *s; int sp;
+    __device__ __forceinline__ void push(uint32_t v) { s[sp * BLOCK] = v; sp++; }
+    __device__ __forceinline__ uint32_t pop() { sp--; return s[sp * BLOCK]; }
+};
+
+// K4  mesh BLAS (bvh.rs:100-151 over Triangle items).  The reference visits both children with the
+// caller's [tmin,tmax] and keeps the smaller t, the right/later item winning ties.  Here: in-order DFS,
+// boxes are culled against the best t so far (which cannot remove the eventual winner except when it
+// lies exactly on a box's entry plane), every triangle is still tested against the caller's tmax, and
+// a later triangle replaces the current one unless current.t < t — the same winner.
+__device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32_t tri_base, const Ray &r, float tmin,
+                                         float tmax, uint32_t *stack_base, float &t_out, uint32_t &tri_out) {
+    V3 inv = mk(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+    LdsStack st{stack_base, 0};
+    bool have = false; float best = tmax; uint32_t best_tri = 0;
+    uint32_t node = root;
+    for (;;) {
+        float4 lo = sc.blas[2 * (size_t)node], hi = sc.blas[2 * (size_t)node + 1];
+        if (hit_aabb(lo, hi, r.o, inv, tmin, have ? best : tmax)) {
+            uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
+            uint32_t kind = A >> 30;
+            if (kind == 0) { st.push(A & NODE_MASK); node = node + 1; continue; }
+            uint32_t items[2] = {A & NODE_MASK, B};
+            int n_items = (kind == NODE_DOUBLE) ? 2 : 1;
+            for (int q = 0; q < n_items; q++) {
+                const float4 *tp = sc.tri + 3 * (size_t)(tri_base + items[q]);
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, b0, b1, b2;
+                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), r, tmin, tmax, t, b0, b1, b2)) {
+                    if (!have || !(best < t)) { have = true; best = t; best_tri = items[q]; }
+                }
+            }
+        }
+        if (st.sp == 0) break;
+        node = st.pop();
+    }
+    t_out = best; tri_out = best_tri;
+    return have;
+}
+
+// shape dispatch in object space.  prim: rect3d face / mesh triangle, else 0.
+__device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float4 q3, float4 q4, uint32_t aux0, uint32_t aux1,
+                                          const Ray &r, float tmin, float tmax, uint32_t *stack_base, float &t, uint32_t &prim) {
+    prim = 0;
+    switch (kind) {
+    case 0: return hit_sphere(q3.x, r, tmin, tmax, t);
+    case 1: case 2: case 3: return hit_rect_kind(kind, q3, q4.x, r, tmin, tmax, t);
+    case 4: return hit_rect3d(q3, q4, r, tmin, tmax, t, prim);
+    case 5: return hit_mesh(sc, aux0, aux1, r, tmin, tmax, stack_base, t, prim);
+    default: return false;
+    }
+}
+
+// objects/volume.rs:56-82
+__device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const Ray &r, float tmin, float tmax,
+                                           uint32_t *stack_base, const RngKey &key, uint32_t segment, uint32_t obj_index, float &t_out) {
+    const float FMAX = 3.40282347e+38f;
+    uint32_t ik = obj_inner(o), prim;
+    float t1, t2;
+    if (!hit_shape(sc, ik, o.q3, o.q4, o.aux0, o.aux1, r, -FMAX, FMAX, stack_base, t1, prim)) return false;
+    if (!hit_shape(sc, ik, o.q3, o.q4, o.aux0, o.aux1, r, t1 + 0.0001f, FMAX, stack_base, t2, prim)) return false;
+    t1 = fmaxf(t1, tmin);
+    t2 = fminf(t2, tmax);
+    if (t1 >= t2) return false;
+    t1 = fmaxf(t1, 0.f);
+    float dmag = mag(r.d);
+    float dist_inside_boundary = (t2 - t1) * dmag;
+    float xi = u2f(draw(key, P_VOLUME, segment, obj_index).x);
+    float hit_distance = -(1.f / o.q4.w) * log10f(xi);          // log10, as written (volume.rs:67)
+    if (hit_distance < dist_inside_boundary) { t_out = t1 + hit_distance / dmag; return true; }
+    return false;
+}
+
+// RenderObjectInternal::hit up to the object-space t (the world-space point/normal are rebuilt in k_shade)
+__device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint32_t obj_index, const Ray &world, float tmin,
+                                           float tmax, uint32_t *stack_base, const RngKey &key, uint32_t segment, float &t, uint32_t &prim) {
+    Ray r = to_object_space(o, world);
+    uint32_t kind = obj_kind(o);
+    if (kind == 6) { prim = 0; return hit_medium(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
+    return hit_shape(sc, kind, o.q3, o.q4, o.aux0, o.aux1, r, tmin, tmax, stack_base, t, prim);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2  extend: closest hit of every queued ray
+// ------------------------------------------------------------------------------------------------
+extern __shared__ uint32_t lds_stack[];
+
+template <bool USE_BVH>
+__global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, DFrame f, DPaths in, float4 *__restrict__ hits,
+                                                  const uint32_t *__restrict__ counts, int segment, int tlas_levels) {
+    const uint32_t n = counts[segment];
+    uint32_t *my_stack = lds_stack + threadIdx.x;                    // [level][lane]
+    uint32_t *blas_stack = my_stack + (size_t)tlas_levels * BLOCK;   // BLAS levels sit above the TLAS levels
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        float4 ra = in.ray_a[i]; float2 rb = in.ray_b[i];
+        Ray r{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
+        RngKey key{0, 0, 0};
+        if (sc.has_medium) key = key_of(f, __float_as_uint(in.state[i].w));
+        const float TMIN = 0.001f, TMAX = 2e9f;                      // render.rs:19
+        float best_t = TMAX; uint32_t best_obj = MISS, best_prim = 0;
+        if (!USE_BVH) {
+            // scene.rs:137-149: linear scan with narrowing; a later object replaces on t <= closest
+            for (uint32_t j = 0; j < sc.n_objects; j++) {
+                Obj o = load_obj(sc.obj, j);
+                float t; uint32_t prim;
+                if (hit_object(sc, o, j, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = j; best_prim = prim; }
+            }
+        } else {
+            // bvh.rs:88-98,115-151 over RenderObjectInternal items; same in-order scheme as hit_mesh
+            V3 inv = mk(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+            LdsStack st{my_stack, 0};
+            bool have = false;
+            uint32_t node = 0;
+            for (;;) {
+                float4 lo = sc.tlas[2 * (size_t)node], hi = sc.tlas[2 * (size_t)node + 1];
+                if (hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX)) {
+                    uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
+                    uint32_t kind = A >> 30;
+                    if (kind == 0) { st.push(A & NODE_MASK); node = node + 1; continue; }
+                    uint32_t items[2] = {A & NODE_MASK, B};
+                    int n_items = (kind == NODE_DOUBLE) ? 2 : 1;
+                    for (int q = 0; q < n_items; q++) {
+                        Obj o = load_obj(sc.obj, items[q]);
+                        float t; uint32_t prim;
+                        if (hit_object(sc, o, items[q], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+                            if (!have || !(best_t < t)) { have = true; best_t = t; best_obj = items[q]; best_prim = prim; }
+                        }
+                    }
+                }
+                if (st.sp == 0) break;
+                node = st.pop();
+            }
+        }
+        hits[i] = make_float4(best_t, __uint_as_float(best_obj), __uint_as_float(best_prim), 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5/K6  shading: textures, materials, environment
+// ------------------------------------------------------------------------------------------------
+__constant__ uint8_t PERM[256] = {   // texture.rs:80-106
+    151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10,
+    23, 190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87,
+    174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211,
+    133, 230, 220, 105, 92, 41, 55, 46, 245, 40, 244, 102, 143, 54, 65, 25, 63, 161, 1, 216, 80, 73, 209, 76, 132, 187, 208,
+    89, 18, 169, 200, 196, 135, 130, 116, 188, 159, 86, 164, 100, 109, 198, 173, 186, 3, 64, 52, 217, 226, 250, 124, 123, 5,
+    202, 38, 147, 118, 126, 255, 82, 85, 212, 207, 206, 59, 227, 47, 16, 58, 17, 182, 189, 28, 42, 223, 183, 170, 213, 119,
+    248, 152, 2, 44, 154, 163, 70, 221, 153, 101, 155, 167, 43, 172, 9, 129, 22, 39, 253, 19, 98, 108, 110, 79, 113, 224, 232,
+    178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249,
+    14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205,
+    93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
+__device__ __forceinline__ uint32_t P(uint32_t i) { return PERM[i & 255u]; }
+// Rust `f32 as usize & 255`: saturating cast (negatives and NaN -> 0, huge -> usize::MAX -> 255)
+__device__ __forceinline__ uint32_t lattice(float fl) {
+    if (!(fl > 0.f)) return 0u;
+    if (fl >= 18446744073709551616.f) return 255u;
+    return (uint32_t)((unsigned long long)fl & 255ull);
+}
+__device__ __forceinline__ float fade(float t) { return t * t * (3.f - 2.f * t); }
+__device__ __forceinline__ float plerp(float t, float a, float b) { return a + t * (b - a); }
+__device__ __forceinline__ float grad(uint32_t hash, float x, float y, float z) {
+    uint32_t h = hash & 15u;
+    float u = h < 8 ? x : y;
+    float v = h < 4 ? y : ((h == 12 || h == 14) ? x : z);
+    u = (h & 1) == 0 ? u : -u;
+    v = (h & 2) == 0 ? v : -v;
+    return u + v;
+}
+__device__ float perlin_noise(V3 p) {    // texture.rs:113-158
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    uint32_t x0 = lattice(fx), y0 = lattice(fy), z0 = lattice(fz);
+    float x = p.x - fx, y = p.y - fy, z = p.z - fz;
+    float u = fade(x), v = fade(y), w = fade(z);
+    uint32_t a = P(x0) + y0, aa = P(a) + z0, ab = P(a + 1) + z0;
+    uint32_t b = P(x0 + 1) + y0, ba = P(b) + z0, bb = P(b + 1) + z0;
+    return plerp(w,
+        plerp(v, plerp(u, grad(P(aa), x, y, z), grad(P(ba), x - 1.f, y, z)),
+                 plerp(u, grad(P(ab), x, y - 1.f, z), grad(P(bb), x - 1.f, y - 1.f, z))),
+        plerp(v, plerp(u, grad(P(aa + 1), x, y, z - 1.f), grad(P(ba + 1), x - 1.f, y, z - 1.f)),
+                 plerp(u, grad(P(ab + 1), x, y - 1.f, z - 1.f), grad(P(bb + 1), x - 1.f, y - 1.f, z - 1.f))));
+}
+__device__ float turb(uint32_t depth, V3 point) {    // texture.rs:206-217
+    float accum = 0.f, weight = 1.f; V3 p = point;
+    for (uint32_t i = 0; i < depth; i++) { accum += weight * perlin_noise(p); weight *= 0.5f; p = p * 2.f; }
+    return accum;
+}
+__device__ __forceinline__ uint32_t sat_u32(float f) { if (!(f > 0.f)) return 0u; if (f >= 4294967296.f) return 0xffffffffu; return (uint32_t)f; }
+
+// Texture::sample (texture.rs).  Checker recursion is unrolled into a bounded walk.
+__device__ V3 texture_sample(const DScene &sc, uint32_t tex, float u, float v, V3 p) {
+    for (int guard = 0; guard < 16; guard++) {
+        float4 t0 = sc.tex[2 * (size_t)tex], t1 = sc.tex[2 * (size_t)tex + 1];
+        uint32_t kind = __float_as_uint(t0.x);
+        float scale = t0.y; uint32_t depth = __float_as_uint(t0.z);
+        switch (kind) {
+        case 0: return mk(t1.x, t1.y, t1.z);                                          // texture.rs:29-34
+        case 1: {                                                                      // texture.rs:57-73
+            float prod = 1.0f;
+            prod = prod * sinf(scale * p.x); prod = prod * sinf(scale * p.y); prod = prod * sinf(scale * p.z);
+            bool positive = (__float_as_uint(prod) >> 31) == 0u;                       // is_sign_positive
+            tex = positive ? __float_as_uint(t1.x) : __float_as_uint(t0.w);
+            continue; }
+        case 2: { float a = perlin_noise(p * scale); float c = fminf(a + 0.5f, 1.f); return mk(c, c, c); }   // texture.rs:161-168
+        case 3: { float c = turb(depth, p * scale); return mk(c, c, c); }                                    // texture.rs:219-225
+        case 4: { float c = 0.5f * (1.f + sinf(scale * p.z + 10.f * turb(depth, p))); return mk(c, c, c); }  // texture.rs:239-249
+        case 5: {                                                                      // texture.rs:296-309
+            uint32_t off = __float_as_uint(t1.x), w = __float_as_uint(t1.y), h = __float_as_uint(t1.z);
+            float fi = u * (float)w, fj = (1.f - v) * (float)h;
+            uint32_t i = min(sat_u32(fi), w - 1), j = min(sat_u32(fj), h - 1);
+            const uint8_t *c = sc.images + off + 3 * ((size_t)j * w + i);
+            return mk((float)c[0], (float)c[1], (float)c[2]) / 255.f; }
+        default: return mk(0.f, 0.f, 0.f);
+        }
+    }
+    return mk(0.f, 0.f, 0.f);
+}
+
+constexpr float PI_F = 3.14159265358979323846f;
+__device__ __forceinline__ void sphere_uv(V3 p, float &u, float &v) {   // objects/sphere.rs:22-29
+    float phi = atan2f(p.z, p.x);
+    float theta = asinf(p.y);
+    u = 1.f - (phi + PI_F) / (2.f * PI_F);
+    v = (theta + PI_F / 2.f) / PI_F;
+}
+
+__device__ V3 env_sample(const DEnv &e, V3 dir) {     // environment.rs:21-26,60-67; examples/hdri_test.rs:70-82
+    if (e.kind == 0) return mk(e.color[0], e.color[1], e.color[2]);
+    if (e.kind == 1) {
+        float t = 0.5f * (dir.y + 1.0f);
+        return (1.f - t) * mk(e.horizon[0], e.horizon[1], e.horizon[2]) + t * mk(e.zenith[0], e.zenith[1], e.zenith[2]);
+    }
+    float u, v; sphere_uv(dir, u, v);
+    float width = (float)e.hdr_w, height = (float)e.hdr_h;
+    auto sat64 = [](float f) -> unsigned long long { if (!(f > 0.f)) return 0ull; if (f >= 18446744073709551616.f) return ~0ull; return (unsigned long long)f; };
+    unsigned long long x = sat64(u * width), y = sat64((1.f - v) * height);
+    unsigned long long idx = sat64((float)y * width) + x;
+    unsigned long long n = (unsigned long long)e.hdr_w * e.hdr_h;
+    if (idx >= n) idx = n - 1;     // the reference indexes out of bounds at the poles; clamp
+    const float *c = e.hdr + 3 * idx;
+    return mk(c[0], c[1], c[2]);
+}
+
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - 2.f * dot(v, n) * n; }           // util.rs:54-56
+__device__ __forceinline__ bool refract(V3 v, V3 n, float ni_over_nt, V3 &out) {                 // util.rs:58-67
+    V3 uv = normalized(v);
+    float dt = dot(uv, n);
+    float disc = 1.f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
+    if (disc > 0.f) { out = ni_over_nt * (uv - n * dt) - n * sqrtf(disc); return true; }
+    return false;
+}
+__device__ __forceinline__ float schlick(float cosine, float ref_idx) {                          // util.rs:69-73
+    float r0 = (1.f - ref_idx) / (1.f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.f - r0) * powf(1.f - cosine, 5.f);
+}
+
+// rebuild the RaycastHit (render.rs:35-41) of the recorded (t, object, primitive) in world space
+struct HitInfo { V3 point, normal; float u, v; uint32_t material; };
+
+__device__ __forceinline__ void rect_hitinfo(uint32_t kind, float a_min, float a_max, float b_min, float b_max, bool flip,
+                                             V3 p, V3 &normal, float &u, float &v) {
+    int a1 = (kind == 3) ? 1 : 0, a2 = (kind == 1) ? 1 : 2, ot = (kind == 1) ? 2 : (kind == 2 ? 1 : 0);
+    V3 n = mk(ot == 0 ? 1.f : 0.f, ot == 1 ? 1.f : 0.f, ot == 2 ? 1.f : 0.f);
+    normal = flip ? -n : n;
+    u = (comp(p, a1) - a_min) / (a_max - a_min);
+    v = (comp(p, a2) - b_min) / (b_max - b_min);
+}
+
+__device__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, const Ray &world, float t, uint32_t prim) {
+    Ray r = to_object_space(o, world);
+    uint32_t kind = obj_kind(o), flags = obj_flags(o);
+    HitInfo h; h.material = o.material; h.u = 0.f; h.v = 0.f;
+    V3 p = ray_point(r, t), n = mk(0.f, 1.f, 0.f);
+    switch (kind) {
+    case 0: {                                                                          // sphere.rs:49-56
+        n = p / o.q3.x;
+        sphere_uv(p / o.q3.x, h.u, h.v);
+        break; }
+    case 1: case 2: case 3:
+        rect_hitinfo(kind, o.q3.x, o.q3.y, o.q3.z, o.q3.w, (flags & OF_RECT_FLIP) != 0, p, n, h.u, h.v);
+        break;
+    case 4: {                                                                          // rect3d.rs:18-80
+        float px = o.q3.x, py = o.q3.y, pz = o.q3.z, sx = o.q3.w, sy = o.q4.x, sz = o.q4.y;
+        uint32_t fk = 1 + (prim >> 1);   // faces 0,1 -> XY(1); 2,3 -> XZ(2); 4,5 -> YZ(3)
+        bool flip = (prim & 1) != 0;
+        if (fk == 1) rect_hitinfo(1, px, px + sx, py, py + sy, flip, p, n, h.u, h.v);
+        else if (fk == 2) rect_hitinfo(2, px, px + sx, pz, pz + sz, flip, p, n, h.u, h.v);
+        else rect_hitinfo(3, py, py + sy, pz, pz + sz, flip, p, n, h.u, h.v);
+        break; }
+    case 5: {                                                                          // mesh.rs:196-218
+        const float4 *tp = sc.tri + 3 * (size_t)(o.aux1 + prim);
+        float4 a = tp[0], b = tp[1], c = tp[2];
+        V3 p0 = mk(a.x, a.y, a.z), p1 = mk(b.x, b.y, b.z), p2 = mk(c.x, c.y, c.z);
+        float tt, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+        hit_triangle(p0, p1, p2, r, -3.40282347e+38f, 3.40282347e+38f, tt, b0, b1, b2);   // same e0..e2/det as in k_extend
+        p = b0 * p0 + b1 * p1 + b2 * p2;
+        h.u = b0 * a.w + b1 * b.w + b2 * c.w;
+        if (flags & OF_MESH_ATTR) {
+            const float4 *np_ = sc.tri_nrm + 3 * (size_t)(o.aux1 + prim);
+            float4 na = np_[0], nb = np_[1], nc = np_[2];
+            h.v = b0 * na.w + b1 * nb.w + b2 * nc.w;
+            if (flags & OF_MESH_NORMALS)
+                n = normalized(b0 * mk(na.x, na.y, na.z) + b1 * mk(nb.x, nb.y, nb.z) + b2 * mk(nc.x, nc.y, nc.z));
+            else
+                n = cross(p0 - p2, p1 - p2);
+        } else {
+            h.v = b0 * 0.f + b1 * 0.f + b2 * 1.f;                                      // default uvs (mesh.rs:107)
+            n = cross(p0 - p2, p1 - p2);                                               // unnormalised (mesh.rs:208)
+        }
+        break; }
+    default: break;                                                                    // medium: normal +Y, uv 0 (volume.rs:72-78)
+    }
+    V3 pos = mk(o.q0.w, o.q1.w, o.q2.w);
+    h.point = rot_fwd(o, p) + pos;                                                     // scene.rs:255-256 (always rotated)
+    h.normal = rot_fwd(o, n);
+    if (flags & OF_FLIP) h.normal = -h.normal;
+    return h;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 + K7  shade + stream compaction
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DFrame f, DPaths in, DPaths out, const float4 *__restrict__ hits,
+                                                 float4 *__restrict__ sample_rad, uint32_t *counts, int segment) {
+    __shared__ uint32_t s_wave_cnt[BLOCK / 64];
+    __shared__ uint32_t s_wave_off[BLOCK / 64];
+    const uint32_t n = counts[segment];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
+        if (i < n) {
+            float4 ra = in.ray_a[i]; float2 rb = in.ray_b[i]; float4 st = in.state[i]; float4 hr = hits[i];
+            Ray r{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
+            V3 beta = mk(st.x, st.y, st.z);
+            path_id = __float_as_uint(st.w);
+            uint32_t obj_index = __float_as_uint(hr.y);
+            V3 rad = mk(0.f, 0.f, 0.f);
+            if (obj_index == MISS) {
+                rad = beta * env_sample(sc.env, normalized(r.d));                      // render.rs:31
+            } else {
+                Obj o = load_obj(sc.obj, obj_index);
+                HitInfo h = rebuild_hit(sc, o, r, hr.x, __float_as_uint(hr.z));
+                float4 m0 = sc.mat[2 * (size_t)h.material], m1 = sc.mat[2 * (size_t)h.material + 1];
+                uint32_t mkind = __float_as_uint(m0.x), mtex = __float_as_uint(m0.y);
+                RngKey key = key_of(f, path_id);
+                V3 atten = mk(0.f, 0.f, 0.f);
+                if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
+                    rad = beta * texture_sample(sc, mtex, h.u, h.v, h.point);
+                } else if (segment < 10) {                                             // render.rs:21
+                    switch (mkind) {
+                    case 0: {                                                          // Lambertian material.rs:64-75
+                        V3 target = h.point + h.normal + random_in_unit_sphere(key, segment);
+                        nr = Ray{h.point, target - h.point};
+                        atten = texture_sample(sc, mtex, h.u, h.v, h.point);
+                        alive = true; break; }
+                    case 1: {                                                          // Metal material.rs:90-107
+                        V3 reflected = reflect(r.d, h.normal);
+                        nr = Ray{h.point, reflected + m0.z * random_in_unit_sphere(key, segment)};
+                        atten = mk(m1.x, m1.y, m1.z);
+                        alive = dot(nr.d, h.normal) > 0.f; break; }
+                    case 2: {                                                          // Dielectric material.rs:121-151
+                        float ref_idx = m0.w;
+                        V3 reflected = reflect(r.d, h.normal);
+                        V3 outward; float ni_over_nt, cosine;
+                        float ddn = dot(r.d, h.normal);
+                        if (ddn > 0.f) { outward = -h.normal; ni_over_nt = ref_idx; cosine = ref_idx * ddn / mag(r.d); }
+                        else { outward = h.normal; ni_over_nt = 1.0f / ref_idx; cosine = -ddn / mag(r.d); }
+                        atten = mk(1.f, 1.f, 1.f);
+                        V3 refracted; bool took_refraction = false;
+                        if (refract(r.d, outward, ni_over_nt, refracted)) {
+                            float xi = u2f(draw(key, P_FRESNEL, segment, 0).x);
+                            if (xi > schlick(cosine, ref_idx)) { nr = Ray{h.point, refracted}; took_refraction = true; }
+                        }
+                        if (!took_refraction) nr = Ray{h.point, reflected};
+                        alive = true; break; }
+                    case 4: {                                                          // Isotropic material.rs:197-204
+                        atten = texture_sample(sc, mtex, h.u, h.v, h.point);
+                        nr = Ray{h.point, random_in_unit_sphere(key, segment)};
+                        alive = true; break; }
+                    default: break;
+                    }
+                    nbeta = beta * atten;
+                }
+            }
+            if (!alive) sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, 0.f);   // every path writes exactly once
+        }
+        // ---- K7: compaction — wave ballot + rank, one global atomic per workgroup ------------------
+        unsigned long long mask = __ballot(alive);
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < BLOCK / 64; w++) { s_wave_off[w] = total; total += s_wave_cnt[w]; }
+            uint32_t g = total ? atomicAdd(&counts[segment + 1], total) : 0u;
+            for (int w = 0; w < BLOCK / 64; w++) s_wave_off[w] += g;
+        }
+        __syncthreads();
+        if (alive) {
+            uint32_t dst = s_wave_off[wave] + rank;
+            out.ray_a[dst] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x);
+            out.ray_b[dst] = make_float2(nr.d.y, nr.d.z);
+            out.state[dst] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id));
+        }
+        __syncthreads();   // s_wave_off is rewritten next iteration
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8  accumulate (sample order, deterministic) and resolve
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_accumulate(DFrame f, const float4 *__restrict__ sample_rad, float4 *__restrict__ accum) {
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < f.n_pixels; p += gridDim.x * BLOCK) {
+        float4 a = accum[p];
+        for (uint32_t s = 0; s < f.spp_batch; s++) {            // render.rs:181: total_color += color(...)
+            float4 c = sample_rad[(size_t)s * f.n_pixels + p];
+            a.x += c.x; a.y += c.y; a.z += c.z;
+        }
+        accum[p] = a;
+    }
+}
+
+__device__ __forceinline__ uint8_t sat_u8(float f) { if (!(f > 0.f)) return 0; if (f >= 255.f) return 255; return (uint8_t)f; }
+
+__global__ __launch_bounds__(BLOCK) void k_resolve(DFrame f, const float4 *__restrict__ accum, uint32_t total_spp, float gamma,
+                                                   uint8_t *rgb8, float *gamma_rgb, float *linear_rgb) {
+    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < f.n_pixels; p += gridDim.x * BLOCK) {
+        float4 a = accum[p];
+        V3 total = mk(a.x, a.y, a.z) / (float)total_spp;                             // render.rs:184
+        float ig = 1.f / gamma;
+        V3 g = mk(powf(total.x, ig), powf(total.y, ig), powf(total.z, ig));           // render.rs:186
+        auto clamp01 = [](float x) { return (x != x) ? x : (x < 0.f ? 0.f : (x > 1.f ? 1.f : x)); };
+        g = mk(clamp01(g.x), clamp01(g.y), clamp01(g.z));                             // render.rs:187
+        if (linear_rgb) { linear_rgb[3 * (size_t)p] = total.x; linear_rgb[3 * (size_t)p + 1] = total.y; linear_rgb[3 * (size_t)p + 2] = total.z; }
+        if (gamma_rgb) { gamma_rgb[3 * (size_t)p] = g.x; gamma_rgb[3 * (size_t)p + 1] = g.y; gamma_rgb[3 * (size_t)p + 2] = g.z; }
+        if (rgb8) { rgb8[3 * (size_t)p] = sat_u8(g.x * 255.99f); rgb8[3 * (size_t)p + 1] = sat_u8(g.y * 255.99f); rgb8[3 * (size_t)p + 2] = sat_u8(g.z * 255.99f); }   // util.rs:14-23
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------------
+void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPaths out, uint32_t *counts, uint32_t n_paths) {
+    hipLaunchKernelGGL(k_raygen, dim3(c.blocks_other), dim3(BLOCK), 0, c.stream, cam, f, out, counts, n_paths);
+}
+void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float4 *hits, const uint32_t *counts,
+                   int segment, bool use_bvh) {
+    int tl = use_bvh ? c.tlas_depth + 1 : 0;
+    size_t lds = (size_t)(tl + c.blas_depth + 1) * BLOCK * sizeof(uint32_t);
+    if (use_bvh) hipLaunchKernelGGL(k_extend<true>, dim3(c.blocks_extend), dim3(BLOCK), lds, c.stream, sc, f, in, hits, counts, segment, tl);
+    else hipLaunchKernelGGL(k_extend<false>, dim3(c.blocks_extend), dim3(BLOCK), lds, c.stream, sc, f, in, hits, counts, segment, tl);
+}
+void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float4 *hits,
+                  float4 *sample_rad, uint32_t *counts, int segment) {
+    hipLaunchKernelGGL(k_shade, dim3(c.blocks_shade), dim3(BLOCK), 0, c.stream, sc, f, in, out, hits, sample_rad, counts, segment);
+}
+void launch_accumulate(const LaunchCfg &c, const DFrame &f, const float4 *sample_rad, float4 *accum) {
+    hipLaunchKernelGGL(k_accumulate, dim3(c.blocks_other), dim3(BLOCK), 0, c.stream, f, sample_rad, accum);
+}
+void launch_resolve(const LaunchCfg &c, const DFrame &f, const float4 *accum, uint32_t total_spp, float gamma,
+                    uint8_t *rgb8, float *gamma_rgb, float *linear_rgb) {
+    hipLaunchKernelGGL(k_resolve, dim3(c.blocks_other), dim3(BLOCK), 0, c.stream, f, accum, total_spp, gamma, rgb8, gamma_rgb, linear_rgb);
+}
+
+} // namespace fw

@@ -1,0 +1,594 @@
+// fw_runtime.cpp — host side of libfirework_hip.so: the C ABI of include/firework_hip.h.
+//
+//   fw_scene_create : `Scene -> SceneInternal` (reference src/scene.rs:111-135,279-292) flattened to the
+//                     HBM layout of fw_device.h; TLAS/BLAS built with the reference's median split
+//                     (src/bvh.rs:21-71) and stored in DFS order.
+//   fw_render       : the wavefront loop that replaces the rayon pixel loop of src/render.rs:127-161:
+//                     raygen -> 11 x (extend, shade+compact) -> accumulate, per batch of paths; resolve.
+//
+// No CPU rendering path exists here: without a HIP device every entry point fails with FW_ERR_NO_DEVICE.
+#include "../../include/firework_hip.h"
+#include "fw_device.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const std::string &msg) { g_last_error = msg; return status; }
+
+#define HIPCHK(expr)                                                                                           \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            char buf_[512];                                                                                    \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return fail(e_ == hipErrorOutOfMemory ? FW_ERR_OOM : FW_ERR_HIP, buf_);                            \
+        }                                                                                                      \
+    } while (0)
+
+// ---- host-side f32 vector math; same expressions as the reference (and -ffp-contract=off) ------------
+struct V3 { float x, y, z; float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); } };
+inline V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float dot(V3 a, V3 b) { return std::fmaf(a.x, b.x, std::fmaf(a.y, b.y, a.z * b.z)); }
+inline V3 cross(V3 a, V3 b) { return {std::fmaf(a.y, b.z, -a.z * b.y), std::fmaf(a.z, b.x, -a.x * b.z), std::fmaf(a.x, b.y, -a.y * b.x)}; }
+inline V3 normalized(V3 a) { float m = std::sqrt(dot(a, a)); return {a.x / m, a.y / m, a.z / m}; }
+inline V3 vmin(V3 a, V3 b) { return {std::fmin(a.x, b.x), std::fmin(a.y, b.y), std::fmin(a.z, b.z)}; }
+inline V3 vmax(V3 a, V3 b) { return {std::fmax(a.x, b.x), std::fmax(a.y, b.y), std::fmax(a.z, b.z)}; }
+inline V3 tov(const fw_vec3 &v) { return {v.x, v.y, v.z}; }
+
+struct Box { V3 mn, mx; };
+inline Box box_union(const Box &a, const Box &b) { return {vmin(a.mn, b.mn), vmax(a.mx, b.mx)}; }   // aabb.rs:52-57
+inline V3 box_center(const Box &b) { return 0.5f * b.mn + 0.5f * b.mx; }                             // aabb.rs:59-61
+
+inline float bits_f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+// ultraviolet Rotor3::into_matrix; rows[i] = row i of rotation_mat
+void rotor_rows(const fw_rotor3 &r, float rows[3][3]) {
+    float s2 = r.s * r.s, bxy2 = r.xy * r.xy, bxz2 = r.xz * r.xz, byz2 = r.yz * r.yz;
+    float s_bxy = r.s * r.xy, s_bxz = r.s * r.xz, s_byz = r.s * r.yz;
+    float bxz_byz = r.xz * r.yz, bxy_byz = r.xy * r.yz, bxy_bxz = r.xy * r.xz;
+    float c0[3] = {s2 - bxy2 - bxz2 + byz2, -2.f * (bxz_byz + s_bxy), 2.f * (bxy_byz - s_bxz)};
+    float c1[3] = {2.f * (s_bxy - bxz_byz), s2 - bxy2 + bxz2 - byz2, -2.f * (s_byz + bxy_bxz)};
+    float c2[3] = {2.f * (s_bxz + bxy_byz), 2.f * (s_byz - bxy_bxz), s2 + bxy2 - bxz2 - byz2};
+    for (int i = 0; i < 3; i++) { rows[i][0] = c0[i]; rows[i][1] = c1[i]; rows[i][2] = c2[i]; }
+}
+inline V3 mat_mul(const float rows[3][3], V3 v) {   // Mat3 * Vec3: c0*x + c1*y + c2*z
+    return {rows[0][0] * v.x + rows[0][1] * v.y + rows[0][2] * v.z,
+            rows[1][0] * v.x + rows[1][1] * v.y + rows[1][2] * v.z,
+            rows[2][0] * v.x + rows[2][1] * v.y + rows[2][2] * v.z};
+}
+
+// ---- K10: flat BVH builder reproducing bvh.rs:21-71 ---------------------------------------------------
+struct FlatBvh {
+    std::vector<float> nodes;   // 8 floats per node
+    uint32_t depth = 0;
+    uint32_t count() const { return (uint32_t)(nodes.size() / 8); }
+};
+struct NanError {};
+
+uint32_t bvh_build_rec(FlatBvh &out, const std::vector<Box> &boxes, uint32_t *idx, size_t n, uint32_t depth, Box &node_box) {
+    int axis = (int)(depth % 3);
+    for (size_t i = 0; i < n; i++) { float c = box_center(boxes[idx[i]])[axis]; if (c != c) throw NanError(); }
+    // Rust's sort_by is stable; the sub-slice is re-sorted at every level (bvh.rs:29-35)
+    std::stable_sort(idx, idx + n, [&](uint32_t a, uint32_t b) { return box_center(boxes[a])[axis] < box_center(boxes[b])[axis]; });
+    uint32_t me = out.count();
+    out.nodes.resize(out.nodes.size() + 8);
+    out.depth = std::max(out.depth, depth);
+    uint32_t A, B = 0;
+    if (n == 1) { node_box = boxes[idx[0]]; A = (fw::NODE_LEAF << 30) | idx[0]; }
+    else if (n == 2) { node_box = box_union(boxes[idx[0]], boxes[idx[1]]); A = (fw::NODE_DOUBLE << 30) | idx[0]; B = idx[1]; }
+    else {
+        size_t half = n / 2;
+        Box lb, rb;
+        bvh_build_rec(out, boxes, idx, half, depth + 1, lb);            // left child = me + 1
+        uint32_t right = bvh_build_rec(out, boxes, idx + half, n - half, depth + 1, rb);
+        node_box = box_union(lb, rb);
+        A = right;
+    }
+    float *p = &out.nodes[(size_t)me * 8];
+    p[0] = node_box.mn.x; p[1] = node_box.mn.y; p[2] = node_box.mn.z; p[3] = bits_f(A);
+    p[4] = node_box.mx.x; p[5] = node_box.mx.y; p[6] = node_box.mx.z; p[7] = bits_f(B);
+    return me;
+}
+Box bvh_build(FlatBvh &out, const std::vector<Box> &boxes) {
+    std::vector<uint32_t> idx(boxes.size());
+    for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)i;
+    Box root;
+    bvh_build_rec(out, boxes, idx.data(), idx.size(), 0, root);
+    return root;
+}
+
+// ---- device allocations owned by a scene / workspace ----------------------------------------------------
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    int alloc(size_t n) {
+        if (n <= bytes && p) return FW_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (n == 0) return FW_OK;
+        HIPCHK(hipMalloc(&p, n));
+        bytes = n;
+        return FW_OK;
+    }
+    int upload(const void *src, size_t n) {
+        int rc = alloc(n ? n : 16);
+        if (rc) return rc;
+        if (n) HIPCHK(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+        return FW_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+} // namespace
+
+struct fw_scene {
+    int device = 0;
+    int n_cus = 256;
+    fw::DScene d{};
+    DevBuf obj, tlas, blas, tri, tri_attr, mat, tex, images, hdr;
+    uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0;
+    bool hdr_env = false;
+    // workspace (grown on demand, reused across fw_render calls)
+    DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, accum, counts, pixel_ids, out_rgb8, out_gamma, out_linear;
+    std::vector<hipEvent_t> events;
+    ~fw_scene() {
+        for (DevBuf *b : {&obj, &tlas, &blas, &tri, &tri_attr, &mat, &tex, &images, &hdr, &ray_a[0], &ray_a[1], &ray_b[0], &ray_b[1],
+                          &state[0], &state[1], &hits, &sample_rad, &accum, &counts, &pixel_ids, &out_rgb8, &out_gamma, &out_linear})
+            b->release();
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+};
+
+namespace {
+
+struct ShapeParams { float q3[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0}; uint32_t kind = 0, flags = 0, aux0 = 0, aux1 = 0; Box box{}; };
+
+struct Flattener {
+    const fw_scene_desc *d;
+    std::vector<float> tri, tri_attr;     // 12 floats per triangle each
+    bool any_attr = false;
+    FlatBvh blas;
+    uint32_t blas_depth = 0;
+
+    int check_material(int32_t m) const { return (m < 0 || (uint32_t)m >= d->n_materials) ? FW_ERR_BAD_ARG : FW_OK; }
+
+    // object-space shape -> parameters + bounding box (Hitable::bounding_box of each shape)
+    int shape_params(int32_t si, ShapeParams &sp, int nest) {
+        if (si < 0 || (uint32_t)si >= d->n_shapes) return fail(FW_ERR_BAD_ARG, "shape index out of range");
+        const fw_shape &s = d->shapes[si];
+        if (s.kind != FW_SHAPE_CONSTANT_MEDIUM || nest > 0) { if (check_material(s.material)) return fail(FW_ERR_BAD_ARG, "material index out of range"); }
+        sp.kind = (uint32_t)s.kind;
+        switch (s.kind) {
+        case FW_SHAPE_SPHERE:                                        // sphere.rs:62-64
+            sp.q3[0] = s.radius;
+            sp.box = {{-s.radius, -s.radius, -s.radius}, {s.radius, s.radius, s.radius}};
+            // the reference builds the box as -Vec3::one()*r .. Vec3::one()*r: same values
+            return FW_OK;
+        case FW_SHAPE_XYRECT: case FW_SHAPE_XZRECT: case FW_SHAPE_YZRECT: {   // rect.rs:75-85
+            sp.q3[0] = s.a_min; sp.q3[1] = s.a_max; sp.q3[2] = s.b_min; sp.q3[3] = s.b_max; sp.q4[0] = s.k;
+            if (s.flip_normal) sp.flags |= fw::OF_RECT_FLIP;
+            int a1 = s.kind == FW_SHAPE_YZRECT ? 1 : 0, a2 = s.kind == FW_SHAPE_XYRECT ? 1 : 2, ot = s.kind == FW_SHAPE_XYRECT ? 2 : (s.kind == FW_SHAPE_XZRECT ? 1 : 0);
+            float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+            mn[a1] = s.a_min; mn[a2] = s.b_min; mn[ot] = s.k - 0.01f;
+            mx[a1] = s.a_max; mx[a2] = s.b_max; mx[ot] = s.k + 0.01f;
+            sp.box = {{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}};
+            return FW_OK; }
+        case FW_SHAPE_RECT3D:                                        // rect3d.rs:102-104
+            sp.q3[0] = s.pos.x; sp.q3[1] = s.pos.y; sp.q3[2] = s.pos.z; sp.q3[3] = s.size.x; sp.q4[0] = s.size.y; sp.q4[1] = s.size.z;
+            sp.box = {tov(s.pos), tov(s.pos) + tov(s.size)};
+            return FW_OK;
+        case FW_SHAPE_TRIANGLE_MESH: return mesh_params(s, sp);
+        case FW_SHAPE_CONSTANT_MEDIUM: {                             // volume.rs:84-86: bbox of the inner shape
+            if (nest > 0) return fail(FW_ERR_UNSUPPORTED, "ConstantMedium nested in a ConstantMedium");
+            ShapeParams in;
+            int rc = shape_params(s.inner, in, nest + 1);
+            if (rc) return rc;
+            if (in.kind == FW_SHAPE_CONSTANT_MEDIUM) return fail(FW_ERR_UNSUPPORTED, "ConstantMedium nested in a ConstantMedium");
+            if (check_material(s.material)) return fail(FW_ERR_BAD_ARG, "material index out of range");
+            sp = in;
+            sp.kind = FW_SHAPE_CONSTANT_MEDIUM | (in.kind << 16);   // inner kind travels in bits 16..23 until packing
+            sp.q4[3] = s.density;
+            return FW_OK; }
+        default: return fail(FW_ERR_BAD_ARG, "unknown shape kind");
+        }
+    }
+
+    // mesh.rs:21-30,221-242: gather triangles, build the mesh's own BVH (always, even with use_bvh=false)
+    int mesh_params(const fw_shape &s, ShapeParams &sp) {
+        if (!s.verts || !s.indices || s.n_indices % 3) return fail(FW_ERR_BAD_ARG, "TriangleMesh needs verts and 3*k indices");
+        if (s.n_indices == 0) return fail(FW_ERR_EMPTY_SCENE, "TriangleMesh with no triangles (reference: unbounded recursion in bvh.rs:29-70)");
+        uint32_t n_tris = s.n_indices / 3, tri_base = (uint32_t)(tri.size() / 12);
+        if ((uint64_t)tri_base + n_tris > fw::NODE_MASK) return fail(FW_ERR_UNSUPPORTED, "too many triangles");
+        bool attr = s.normals || s.uvs;
+        std::vector<Box> boxes(n_tris);
+        tri.resize(tri.size() + (size_t)n_tris * 12);
+        if (attr) any_attr = true;
+        tri_attr.resize(tri.size(), 0.f);
+        for (uint32_t t = 0; t < n_tris; t++) {
+            V3 p[3];
+            for (int k = 0; k < 3; k++) {
+                uint32_t vi = s.indices[3 * t + k];
+                if (vi >= s.n_verts) return fail(FW_ERR_BAD_ARG, "vertex index out of range");
+                p[k] = {s.verts[3 * vi], s.verts[3 * vi + 1], s.verts[3 * vi + 2]};
+                float *o = &tri[(size_t)(tri_base + t) * 12 + 4 * k];
+                o[0] = p[k].x; o[1] = p[k].y; o[2] = p[k].z;
+                o[3] = s.uvs ? s.uvs[2 * vi] : (k == 1 ? 1.f : 0.f);        // default uvs (0,0),(1,0),(0,1) mesh.rs:107
+                float *a = &tri_attr[(size_t)(tri_base + t) * 12 + 4 * k];
+                if (s.normals) { a[0] = s.normals[3 * vi]; a[1] = s.normals[3 * vi + 1]; a[2] = s.normals[3 * vi + 2]; }
+                a[3] = s.uvs ? s.uvs[2 * vi + 1] : (k == 2 ? 1.f : 0.f);
+            }
+            Box b{vmin(p[0], p[1]), vmax(p[0], p[1])};               // from_two_points(p0,p1).expand_to_point(p2)
+            b = {vmin(b.mn, p[2]), vmax(b.mx, p[2])};
+            V3 size = b.mx - b.mn;
+            if (std::fabs(size.x) < 0.001f) { b.mn.x -= 0.001f; b.mx.x += 0.001f; }
+            if (std::fabs(size.y) < 0.001f) { b.mn.y -= 0.001f; b.mx.y += 0.001f; }
+            if (std::fabs(size.z) < 0.001f) { b.mn.z -= 0.001f; b.mx.z += 0.001f; }
+            boxes[t] = b;
+        }
+        FlatBvh local;
+        try { sp.box = bvh_build(local, boxes); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
+        uint32_t root = blas.count();
+        // rebase child links of the local tree into the shared BLAS array
+        for (uint32_t i = 0; i < local.count(); i++) {
+            uint32_t A; std::memcpy(&A, &local.nodes[(size_t)i * 8 + 3], 4);
+            if ((A >> 30) == 0) { A += root; local.nodes[(size_t)i * 8 + 3] = bits_f(A); }
+        }
+        blas.nodes.insert(blas.nodes.end(), local.nodes.begin(), local.nodes.end());
+        blas_depth = std::max(blas_depth, local.depth);
+        sp.aux0 = root; sp.aux1 = tri_base;
+        if (s.normals) sp.flags |= fw::OF_MESH_NORMALS;
+        if (attr) sp.flags |= fw::OF_MESH_ATTR;
+        return FW_OK;
+    }
+};
+
+int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
+    if (!desc || !out) return fail(FW_ERR_BAD_ARG, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FW_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(FW_ERR_BAD_ARG, "device index out of range");
+    if (desc->n_objects == 0 || !desc->objects) return fail(FW_ERR_EMPTY_SCENE, "No render objects added to scene!");
+    if (desc->n_objects > fw::NODE_MASK) return fail(FW_ERR_UNSUPPORTED, "too many objects");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+
+    Flattener fl{desc};
+    std::vector<float> objs((size_t)desc->n_objects * fw::OBJ_Q * 4, 0.f);
+    std::vector<Box> world(desc->n_objects);
+    bool has_medium = false;
+    for (uint32_t i = 0; i < desc->n_objects; i++) {
+        const fw_object &o = desc->objects[i];
+        ShapeParams sp;
+        int rc = fl.shape_params(o.shape, sp, 0);
+        if (rc) return rc;
+        float rows[3][3];
+        rotor_rows(o.rotation, rows);
+        uint32_t flags = sp.flags;
+        float cos_trace = 0.5f * ((rows[0][0] + rows[1][1] + rows[2][2]) - 1.f);     // scene.rs:180-185
+        Box rb = sp.box;
+        if (cos_trace < 0.999f) {
+            flags |= fw::OF_ROTATED;
+            V3 mn = 10e9f * V3{1, 1, 1}, mx = -10e9f * V3{1, 1, 1};                 // scene.rs:188-203
+            for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int c = 0; c < 2; c++) {
+                V3 corner{a == 0 ? sp.box.mn.x : sp.box.mx.x, b == 0 ? sp.box.mn.y : sp.box.mx.y, c == 0 ? sp.box.mn.z : sp.box.mx.z};
+                V3 np = mat_mul(rows, corner);
+                mx = {std::fmax(np.x, mx.x), std::fmax(np.y, mx.y), std::fmax(np.z, mx.z)};
+                mn = {std::fmin(np.x, mn.x), std::fmin(np.y, mn.y), std::fmin(np.z, mn.z)};
+            }
+            rb = {mn, mx};
+        }
+        world[i] = {rb.mn + tov(o.position), rb.mx + tov(o.position)};                // scene.rs:207-210
+        if (o.flip_normals) flags |= fw::OF_FLIP;
+        uint32_t kind = sp.kind & 0xffu, inner = (sp.kind >> 16) & 0xffu;
+        if (kind == FW_SHAPE_CONSTANT_MEDIUM) has_medium = true;
+        int32_t material = desc->shapes[o.shape].material;
+        float *q = &objs[(size_t)i * fw::OBJ_Q * 4];
+        const float pos[3] = {o.position.x, o.position.y, o.position.z};
+        for (int r = 0; r < 3; r++) { q[4 * r] = rows[r][0]; q[4 * r + 1] = rows[r][1]; q[4 * r + 2] = rows[r][2]; q[4 * r + 3] = pos[r]; }
+        std::memcpy(q + 12, sp.q3, 16);
+        std::memcpy(q + 16, sp.q4, 16);
+        q[20] = bits_f(kind | (flags << 8) | (inner << 24));
+        q[21] = bits_f((uint32_t)material);
+        q[22] = bits_f(sp.aux0);
+        q[23] = bits_f(sp.aux1);
+    }
+    FlatBvh tlas;
+    try { bvh_build(tlas, world); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
+
+    // materials / textures / images
+    std::vector<float> mats((size_t)std::max(1u, desc->n_materials) * 8, 0.f), texs((size_t)std::max(1u, desc->n_textures) * 8, 0.f);
+    std::vector<uint8_t> images;
+    for (uint32_t i = 0; i < desc->n_textures; i++) {
+        const fw_texture &t = desc->textures[i];
+        float *q = &texs[(size_t)i * 8];
+        q[0] = bits_f((uint32_t)t.kind); q[1] = t.scale; q[2] = bits_f(t.depth);
+        switch (t.kind) {
+        case FW_TEX_CONSTANT: q[4] = t.color.x; q[5] = t.color.y; q[6] = t.color.z; break;
+        case FW_TEX_CHECKER:
+            if (t.odd < 0 || t.even < 0 || (uint32_t)t.odd >= desc->n_textures || (uint32_t)t.even >= desc->n_textures) return fail(FW_ERR_BAD_ARG, "checker child texture out of range");
+            q[3] = bits_f((uint32_t)t.odd); q[4] = bits_f((uint32_t)t.even); break;
+        case FW_TEX_PERLIN: case FW_TEX_TURBULENCE: case FW_TEX_MARBLE: break;
+        case FW_TEX_IMAGE: {
+            if (!t.img_rgb8 || !t.img_w || !t.img_h) return fail(FW_ERR_BAD_ARG, "ImageTexture without pixels");
+            size_t off = images.size(), nb = (size_t)t.img_w * t.img_h * 3;
+            if (off + nb > 0xffffffffull) return fail(FW_ERR_UNSUPPORTED, "image textures exceed 4 GiB");
+            images.insert(images.end(), t.img_rgb8, t.img_rgb8 + nb);
+            q[4] = bits_f((uint32_t)off); q[5] = bits_f(t.img_w); q[6] = bits_f(t.img_h); break; }
+        default: return fail(FW_ERR_BAD_ARG, "unknown texture kind");
+        }
+    }
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        const fw_material &m = desc->materials[i];
+        float *q = &mats[(size_t)i * 8];
+        if (m.kind < FW_MAT_LAMBERTIAN || m.kind > FW_MAT_ISOTROPIC) return fail(FW_ERR_BAD_ARG, "unknown material kind");
+        bool needs_tex = m.kind == FW_MAT_LAMBERTIAN || m.kind == FW_MAT_EMISSIVE || m.kind == FW_MAT_ISOTROPIC;
+        if (needs_tex && (m.texture < 0 || (uint32_t)m.texture >= desc->n_textures)) return fail(FW_ERR_BAD_ARG, "material texture out of range");
+        q[0] = bits_f((uint32_t)m.kind); q[1] = bits_f((uint32_t)(needs_tex ? m.texture : 0)); q[2] = m.roughness; q[3] = m.ref_idx;
+        q[4] = m.albedo.x; q[5] = m.albedo.y; q[6] = m.albedo.z;
+    }
+    const fw_environment &e = desc->environment;
+    if (e.kind < FW_ENV_COLOR || e.kind > FW_ENV_HDR) return fail(FW_ERR_BAD_ARG, "unknown environment kind");
+    if (e.kind == FW_ENV_HDR && (!e.hdr_rgb || !e.hdr_w || !e.hdr_h)) return fail(FW_ERR_BAD_ARG, "HdrEnv without pixels");
+
+    // stack depth the kernels will be given
+    if (tlas.depth + 1 + fl.blas_depth + 1 > 60) return fail(FW_ERR_BVH_DEPTH, "BVH deeper than the LDS traversal stack (60 levels)");
+
+    fw_scene *sc = new (std::nothrow) fw_scene();
+    if (!sc) return fail(FW_ERR_OOM, "host allocation failed");
+    sc->device = device;
+    sc->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int rc = FW_OK;
+    auto up = [&](DevBuf &b, const void *p, size_t n) { if (!rc) rc = b.upload(p, n); };
+    up(sc->obj, objs.data(), objs.size() * 4);
+    up(sc->tlas, tlas.nodes.data(), tlas.nodes.size() * 4);
+    up(sc->blas, fl.blas.nodes.data(), fl.blas.nodes.size() * 4);
+    up(sc->tri, fl.tri.data(), fl.tri.size() * 4);
+    if (fl.any_attr) up(sc->tri_attr, fl.tri_attr.data(), fl.tri_attr.size() * 4);
+    up(sc->mat, mats.data(), mats.size() * 4);
+    up(sc->tex, texs.data(), texs.size() * 4);
+    up(sc->images, images.data(), images.size());
+    if (e.kind == FW_ENV_HDR) up(sc->hdr, e.hdr_rgb, (size_t)e.hdr_w * e.hdr_h * 3 * 4);
+    if (rc) { delete sc; return rc; }
+    fw::DScene &d = sc->d;
+    d.obj = (const float4 *)sc->obj.p; d.tlas = (const float4 *)sc->tlas.p; d.blas = (const float4 *)sc->blas.p;
+    d.tri = (const float4 *)sc->tri.p; d.tri_nrm = (const float4 *)sc->tri_attr.p;
+    d.mat = (const float4 *)sc->mat.p; d.tex = (const float4 *)sc->tex.p; d.images = (const uint8_t *)sc->images.p;
+    d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u;
+    d.env.kind = e.kind;
+    d.env.color[0] = e.color.x; d.env.color[1] = e.color.y; d.env.color[2] = e.color.z;
+    d.env.zenith[0] = e.zenith.x; d.env.zenith[1] = e.zenith.y; d.env.zenith[2] = e.zenith.z;
+    d.env.horizon[0] = e.horizon.x; d.env.horizon[1] = e.horizon.y; d.env.horizon[2] = e.horizon.z;
+    d.env.hdr = (const float *)sc->hdr.p; d.env.hdr_w = e.hdr_w; d.env.hdr_h = e.hdr_h;
+    sc->hdr_env = e.kind == FW_ENV_HDR;
+    sc->tlas_nodes = tlas.count(); sc->blas_nodes = fl.blas.count();
+    sc->tlas_depth = tlas.depth; sc->blas_depth = fl.blas_depth;
+    *out = sc;
+    return FW_OK;
+}
+
+// camera.rs:74-107
+fw::DCamera make_camera(const fw_camera_settings &s, uint32_t width, uint32_t height) {
+    const float PI_F = 3.14159265358979323846f;
+    float theta = s.vfov * PI_F / 180.f;
+    V3 cam_pos = tov(s.cam_pos), look_at = tov(s.look_at);
+    V3 w = normalized(cam_pos - look_at);
+    V3 u = normalized(cross(V3{0, 1, 0}, w));
+    V3 v = cross(w, u);
+    float half_height = std::tan(theta / 2.0f);
+    float half_width = half_height * (float)width / (float)height;
+    V3 lower_left = cam_pos - half_width * s.focus_dist * u - half_height * s.focus_dist * v - w * s.focus_dist;
+    V3 horizontal = 2.0f * half_width * s.focus_dist * u;
+    V3 vertical = 2.0f * half_height * s.focus_dist * v;
+    fw::DCamera c;
+    auto put = [](float *d, V3 a) { d[0] = a.x; d[1] = a.y; d[2] = a.z; };
+    put(c.position, cam_pos); put(c.horizontal, horizontal); put(c.vertical, vertical); put(c.lower_left, lower_left); put(c.u, u); put(c.v, v);
+    c.lens_radius = s.aperture / 2.f;
+    return c;
+}
+
+uint32_t default_paths_per_batch() {
+    if (const char *e = getenv("FIREWORK_PATHS_PER_BATCH")) { long v = atol(e); if (v > 0) return (uint32_t)v; }
+    return 1u << 22;
+}
+
+int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats) {
+    if (!sc || !p) return fail(FW_ERR_BAD_ARG, "null argument");
+    if (p->width == 0 || p->height == 0 || p->samples == 0) return fail(FW_ERR_BAD_ARG, "width, height and samples must be > 0");
+    if (!(p->gamma > 0.f)) return fail(FW_ERR_BAD_ARG, "gamma must be > 0");
+    if (p->rng_mode != FW_RNG_CTR) return fail(FW_ERR_UNSUPPORTED, "the HIP path implements FW_RNG_CTR only (FW_RNG_LCG is a sequential stream)");
+    uint64_t full = (uint64_t)p->width * p->height;
+    if (full > 0xffffffffull) return fail(FW_ERR_UNSUPPORTED, "image too large");
+    uint32_t n_pix = p->pixel_ids ? p->n_pixels : (uint32_t)full;
+    if (n_pix == 0) return fail(FW_ERR_BAD_ARG, "no pixels to render");
+    if (p->pixel_ids) for (uint32_t i = 0; i < n_pix; i++) if (p->pixel_ids[i] >= full) return fail(FW_ERR_BAD_ARG, "pixel id out of range");
+    HIPCHK(hipSetDevice(sc->device));
+    hipStream_t stream = (hipStream_t)p->stream;
+
+    uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch();
+    uint32_t spp_b = std::max<uint32_t>(1u, budget / n_pix);
+    spp_b = std::min(spp_b, p->samples);
+    uint64_t cap64 = (uint64_t)n_pix * spp_b;
+    if (cap64 > 0x7fffffffull) return fail(FW_ERR_UNSUPPORTED, "too many paths per batch");
+    uint32_t cap = (uint32_t)cap64;
+    uint32_t n_batches = (p->samples + spp_b - 1) / spp_b;
+
+    int rc = FW_OK;
+    auto need = [&](DevBuf &b, size_t n) { if (!rc) rc = b.alloc(n); };
+    for (int k = 0; k < 2; k++) { need(sc->ray_a[k], (size_t)cap * 16); need(sc->ray_b[k], (size_t)cap * 8); need(sc->state[k], (size_t)cap * 16); }
+    need(sc->hits, (size_t)cap * 16);
+    need(sc->sample_rad, (size_t)cap * 16);
+    need(sc->accum, (size_t)n_pix * 16);
+    need(sc->counts, (size_t)n_batches * fw::COUNT_STRIDE * 4);
+    if (p->pixel_ids) need(sc->pixel_ids, (size_t)n_pix * 4);
+    uint8_t *d_rgb8 = rgb8; float *d_gamma = gamma_rgb, *d_linear = linear_rgb;
+    if (!p->outputs_on_device) {
+        if (rgb8) { need(sc->out_rgb8, (size_t)n_pix * 3); d_rgb8 = (uint8_t *)sc->out_rgb8.p; }
+        if (gamma_rgb) { need(sc->out_gamma, (size_t)n_pix * 12); d_gamma = (float *)sc->out_gamma.p; }
+        if (linear_rgb) { need(sc->out_linear, (size_t)n_pix * 12); d_linear = (float *)sc->out_linear.p; }
+    }
+    if (rc) return rc;
+    if (p->pixel_ids) HIPCHK(hipMemcpyAsync(sc->pixel_ids.p, p->pixel_ids, (size_t)n_pix * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetAsync(sc->accum.p, 0, (size_t)n_pix * 16, stream));
+    HIPCHK(hipMemsetAsync(sc->counts.p, 0, (size_t)n_batches * fw::COUNT_STRIDE * 4, stream));
+
+    fw::LaunchCfg cfg;
+    cfg.stream = stream;
+    int max_blocks = sc->n_cus * 8;
+    auto blocks_for = [&](uint64_t n) { return (int)std::max<uint64_t>(1, std::min<uint64_t>((n + fw::BLOCK - 1) / fw::BLOCK, (uint64_t)max_blocks)); };
+    cfg.blocks_extend = blocks_for(cap); cfg.blocks_shade = blocks_for(cap); cfg.blocks_other = blocks_for(cap);
+    cfg.tlas_depth = (int)sc->tlas_depth; cfg.blas_depth = (int)sc->blas_depth;
+
+    fw::DCamera cam = make_camera(p->camera, p->width, p->height);
+    fw::DFrame fr;
+    fr.width = p->width; fr.height = p->height; fr.n_pixels = n_pix;
+    fr.pixel_ids = p->pixel_ids ? (const uint32_t *)sc->pixel_ids.p : nullptr;
+    fr.seed32 = (uint32_t)p->seed ^ ((uint32_t)(p->seed >> 32) * 0x9E3779B9u);
+
+    // events: [0]=start [1]=stop, then per-launch pairs when FW_FLAG_TIME_KERNELS
+    const bool timing = (p->flags & FW_FLAG_TIME_KERNELS) != 0;
+    size_t per_batch_launches = 1 + 2 * fw::MAX_SEGMENTS + 1;
+    size_t n_events = 2 + (timing ? 2 * (per_batch_launches * n_batches + 1) : 0);
+    while (sc->events.size() < n_events) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); sc->events.push_back(e); }
+    size_t ev = 2;
+    std::vector<int> ev_class;   // 0 raygen 1 extend 2 shade 3 accumulate/resolve
+    auto timed = [&](int cls, auto &&launch) {
+        if (timing) (void)hipEventRecord(sc->events[ev], stream);
+        launch();
+        if (timing) { (void)hipEventRecord(sc->events[ev + 1], stream); ev += 2; ev_class.push_back(cls); }
+    };
+
+    fw::DPaths buf[2];
+    for (int k = 0; k < 2; k++) buf[k] = {(float4 *)sc->ray_a[k].p, (float2 *)sc->ray_b[k].p, (float4 *)sc->state[k].p};
+    float4 *hits = (float4 *)sc->hits.p, *srad = (float4 *)sc->sample_rad.p, *accum = (float4 *)sc->accum.p;
+    const bool use_bvh = p->use_bvh != 0;
+
+    HIPCHK(hipEventRecord(sc->events[0], stream));
+    for (uint32_t b = 0; b < n_batches; b++) {
+        fr.sample0 = b * spp_b;
+        fr.spp_batch = std::min(spp_b, p->samples - fr.sample0);
+        uint32_t n_paths = n_pix * fr.spp_batch;
+        uint32_t *counts = (uint32_t *)sc->counts.p + (size_t)b * fw::COUNT_STRIDE;
+        int cur = 0;
+        timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], counts, n_paths); });
+        for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
+            timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, counts, seg, use_bvh); });
+            timed(2, [&] { fw::launch_shade(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], hits, srad, counts, seg); });
+            cur ^= 1;
+        }
+        timed(3, [&] { fw::launch_accumulate(cfg, fr, srad, accum); });
+    }
+    timed(3, [&] { fw::launch_resolve(cfg, fr, accum, p->samples, p->gamma, d_rgb8, d_gamma, d_linear); });
+    HIPCHK(hipEventRecord(sc->events[1], stream));
+    HIPCHK(hipGetLastError());
+
+    std::vector<uint32_t> h_counts((size_t)n_batches * fw::COUNT_STRIDE);
+    HIPCHK(hipMemcpyAsync(h_counts.data(), sc->counts.p, h_counts.size() * 4, hipMemcpyDeviceToHost, stream));
+    if (!p->outputs_on_device) {
+        if (rgb8) HIPCHK(hipMemcpyAsync(rgb8, d_rgb8, (size_t)n_pix * 3, hipMemcpyDeviceToHost, stream));
+        if (gamma_rgb) HIPCHK(hipMemcpyAsync(gamma_rgb, d_gamma, (size_t)n_pix * 12, hipMemcpyDeviceToHost, stream));
+        if (linear_rgb) HIPCHK(hipMemcpyAsync(linear_rgb, d_linear, (size_t)n_pix * 12, hipMemcpyDeviceToHost, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->samples = (uint64_t)n_pix * p->samples;
+        for (uint32_t b = 0; b < n_batches; b++)
+            for (int s = 0; s < fw::MAX_SEGMENTS; s++) { uint64_t c = h_counts[(size_t)b * fw::COUNT_STRIDE + s]; stats->rays_per_depth[s] += c; stats->rays += c; }
+        stats->algorithmic_bytes = 160 * stats->rays + 24 * stats->samples;   // SURVEY §8(d); HDR env misses are added by the caller that knows them
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, sc->events[0], sc->events[1]));
+        stats->ms_render = ms;
+        if (timing) {
+            double acc[4] = {0, 0, 0, 0};
+            for (size_t i = 0; i < ev_class.size(); i++) {
+                float t = 0.f;
+                HIPCHK(hipEventElapsedTime(&t, sc->events[2 + 2 * i], sc->events[3 + 2 * i]));
+                acc[ev_class[i]] += t;
+            }
+            stats->ms_raygen = acc[0]; stats->ms_extend = acc[1]; stats->ms_shade = acc[2]; stats->ms_accumulate = acc[3];
+        }
+        stats->n_extend_launches = n_batches * fw::MAX_SEGMENTS; stats->n_shade_launches = n_batches * fw::MAX_SEGMENTS;
+        stats->n_batches = n_batches; stats->tlas_nodes = sc->tlas_nodes; stats->blas_nodes = sc->blas_nodes;
+    }
+    return FW_OK;
+}
+
+} // namespace
+
+// =========================================================================================================
+extern "C" {
+
+int fw_abi_version(void) { return FW_ABI_VERSION; }
+
+const char *fw_strerror(int s) {
+    switch (s) {
+    case FW_OK: return "ok";
+    case FW_ERR_BAD_ARG: return "bad argument";
+    case FW_ERR_EMPTY_SCENE: return "No render objects added to scene!";
+    case FW_ERR_NAN_BBOX: return "Float comparison failed in BVH constructor";
+    case FW_ERR_MESH_NORMALS: return "TriangleMesh::new() -- normals.len() must equal verts.len()";
+    case FW_ERR_MESH_UVS: return "TriangleMesh::new() -- uvs.len() must equal verts.len()";
+    case FW_ERR_UNSUPPORTED: return "unsupported on the HIP path";
+    case FW_ERR_HIP: return "HIP runtime error";
+    case FW_ERR_NO_DEVICE: return "no HIP device (no CPU fallback exists)";
+    case FW_ERR_BVH_DEPTH: return "BVH deeper than the traversal stack";
+    case FW_ERR_OOM: return "out of memory";
+    default: return "unknown error";
+    }
+}
+
+const char *fw_last_error(void) { return g_last_error.c_str(); }
+
+int fw_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fw_scene_create(const fw_scene_desc *desc, int device, fw_scene **out) {
+    try { return create_scene_impl(desc, device, out); }
+    catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
+    catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_scene_create"); }
+}
+
+void fw_scene_destroy(fw_scene *scene) {
+    if (!scene) return;
+    (void)hipSetDevice(scene->device);
+    delete scene;
+}
+
+int fw_render(fw_scene *scene, const fw_render_params *params, uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats) {
+    try { return render_impl(scene, params, rgb8, gamma_rgb, linear_rgb, stats); }
+    catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
+    catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_render"); }
+}
+
+int fw_render_scene(const fw_scene_desc *desc, const fw_render_params *params, int device, uint8_t *rgb8, float *gamma_rgb,
+                    float *linear_rgb, fw_stats *stats) {
+    auto t0 = std::chrono::steady_clock::now();
+    fw_scene *sc = nullptr;
+    int rc = fw_scene_create(desc, device, &sc);
+    if (rc) return rc;
+    double ms_scene = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    rc = fw_render(sc, params, rgb8, gamma_rgb, linear_rgb, stats);
+    if (!rc && stats) stats->ms_scene = ms_scene;
+    fw_scene_destroy(sc);
+    return rc;
+}
+
+} // extern "C"

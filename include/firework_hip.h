@@ -190,9 +190,12 @@ typedef struct fw_render_params {
     const uint32_t *pixel_ids;
     uint32_t n_pixels;
     uint32_t paths_per_batch;          /* wavefront pool size; 0 = library default */
+    uint32_t flags;                    /* FW_FLAG_* */
     int32_t outputs_on_device;         /* !=0: the three output pointers are device pointers */
     void *stream;                      /* hipStream_t to launch on, NULL = default stream    */
 } fw_render_params;
+
+#define FW_FLAG_TIME_KERNELS 1u  /* bracket every launch with HIP events and fill fw_stats.ms_<class> */
 
 #define FW_MAX_SEGMENTS 11  /* depths 0..10: render.rs:21 */
 
