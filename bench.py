@@ -12,6 +12,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                  be built in this image) timed on this host's cores on a bounded sample of the same scene
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -34,7 +35,7 @@ def main():
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--paths-per-batch", type=int, default=0)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events (no roofline object)")
-    ap.add_argument("--cpu-spp", type=int, default=96, help="spp of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -114,18 +115,36 @@ def main():
             "rays_per_sample": total_rays / max(1.0, total_samples),
         }
         if not args.no_kernel_timing:
-            # rank-0 kernel classes (every rank runs the same kernels on 1/N of the pixels)
-            rays0 = acc["rays"]
-            ext_bytes = 40.0 * rays0          # extend: reads ray 24 B, writes hit 16 B      
-            shd_bytes = 120.0 * rays0         # shade: ray 24 + hit 16 + state 24 in, ray 24 + state 24 out, 8 queue
+            # rank-0 kernel classes (every rank runs the same kernels on 1/N of the pixels).
+            # Algorithmic HBM bytes of THIS implementation's layout, exact from the counters:
+            #   k_extend: reads ray 24 B, writes hit 16 B                         -> 40 B per ray
+            #   k_shade : reads ray 24 + hit 16 + state 16; writes ray 24 + state 16 per continuing path,
+            #             radiance 16 per terminated path                        -> 96*rays - 24*samples
+            # (SURVEY §8d's generic figure is 40 + 120 = 160 B/ray; this layout moves fewer bytes.)
+            rays0, samples0 = acc["rays"], acc["samples"]
+            ext_bytes = 40.0 * rays0
+            shd_bytes = 96.0 * rays0 - 24.0 * samples0
             ext_s, shd_s = acc["ms_extend"] / 1e3, acc["ms_shade"] / 1e3
             dom = "k_extend" if ext_s >= shd_s else "k_shade"
             b, t = (ext_bytes, ext_s) if dom == "k_extend" else (shd_bytes, shd_s)
             ach = b / t / 1e9 if t > 0 else 0.0
+            launches = max(1, acc["n_extend_launches"])
+            traffic, traffic_src = None, None
+            pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+            if pmcs:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+                try:
+                    pk = json.load(open(pmcs[-1]))["kernels"]
+                    key = [k for k in pk if dom in k][0]
+                    traffic, traffic_src = pk[key]["hbm_bytes_per_launch"], os.path.relpath(pmcs[-1], ROOT)
+                except Exception:
+                    pass
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                               "avg_launch_us": t * 1e6 / max(1, acc["n_extend_launches"]),
-                               "bytes_per_ray": 40 if dom == "k_extend" else 120}
+                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                               "algorithmic_bytes_per_launch": b / launches,
+                               "avg_launch_us": t * 1e6 / launches,
+                               "bytes_per_ray": b / max(1.0, rays0),
+                               "other_kernel": {"kernel": "k_shade" if dom == "k_extend" else "k_extend",
+                                                "achieved": ((shd_bytes / shd_s) if dom == "k_extend" else (ext_bytes / ext_s)) / 1e9 if min(ext_s, shd_s) > 0 else 0.0}}
             frame_bytes = 160.0 * rays0 + 24.0 * acc["samples"]
             out["roofline_frame"] = {"achieved": frame_bytes / (acc["ms_render"] / 1e3) / 1e9, "unit": "GB/s",
                                      "frac": frame_bytes / (acc["ms_render"] / 1e3) / 1e9 / HBM_PEAK_GBS,
@@ -134,14 +153,16 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             from oracle import oracle_binding as ob       # CPU oracle: the checker, timed as the reported baseline
             from firework_amd._abi import FW_RNG_LCG
-            cscene, cr = scenes.config(args.config, args.width, args.height, args.cpu_spp)
-            cores = os.cpu_count() or 1
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            # bounded sample: ~15 s of CPU work at ~0.55 Msamples/s per core on this scene
+            cpu_spp = args.cpu_spp or max(16, min(s["samples"], int(15.0 * 0.55e6 * cores / (s["width"] * s["height"]))))
+            cscene, cr = scenes.config(args.config, args.width, args.height, cpu_spp)
             c0 = time.perf_counter()
             cres = ob.render(cscene, cr, rng_mode=FW_RNG_LCG, n_threads=cores)   # reference semantics: per-pixel sequential LCG
             cdt = time.perf_counter() - c0
             out["cpu_baseline"] = {"value": cres.stats["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
                                    "msamples_per_s": cres.stats["samples"] / cdt / 1e6,
-                                   "sample": f"{args.config} {cr.settings['width']}x{cr.settings['height']} @{args.cpu_spp}spp "
+                                   "sample": f"{args.config} {cr.settings['width']}x{cr.settings['height']} @{cpu_spp}spp "
                                              f"({cres.stats['samples']} samples, {cdt:.1f} s; cost is linear in spp)"}
         print(json.dumps(out))
     tr.close()

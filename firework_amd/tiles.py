@@ -24,55 +24,63 @@ def tile_pixel_ids(width, height, rank, world, tile=TILE):
     return np.concatenate(ids) if ids else np.zeros(0, np.uint32)
 
 
-def max_tile_pixels(width, height, world, tile=TILE):
-    return max(int(tile_pixel_ids(width, height, r, world, tile).shape[0]) for r in range(world))
+class TileGather:
+    """Rank bookkeeping + the one collective.  Device-agnostic (cuda tensors with nccl, cpu tensors with gloo)."""
+
+    def __init__(self, width, height, rank, world, device, dist=None, tile=TILE):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.width, self.height, self.rank, self.world, self.device = width, height, rank, world, device
+        all_ids = [tile_pixel_ids(width, height, r, world, tile) for r in range(world)]
+        self.ids = np.ascontiguousarray(all_ids[rank])
+        self.counts = [int(a.shape[0]) for a in all_ids]
+        self.n_local, self.n_max = self.counts[rank], max(self.counts)
+        self.local = torch.zeros((self.n_max, 3), dtype=torch.uint8, device=device)   # padded to equal size for gather
+        self.frame = None
+        if rank == 0:
+            self.frame = torch.zeros((width * height, 3), dtype=torch.uint8, device=device)
+            self.all_ids_dev = [torch.from_numpy(a.astype(np.int64)).to(device) for a in all_ids]
+            if world > 1:
+                self.gather_list = [torch.zeros((self.n_max, 3), dtype=torch.uint8, device=device) for _ in range(world)]
+
+    def assemble(self):
+        """`self.local[:n_local]` holds this rank's finished pixels -> full frame on rank 0 (None elsewhere)."""
+        if self.world == 1:
+            self.frame.index_copy_(0, self.all_ids_dev[0], self.local[: self.n_local])
+            return self.frame
+        # the only collective of the whole path: <= W*H*3 bytes in total
+        self.dist.gather(self.local, self.gather_list if self.rank == 0 else None, dst=0)
+        if self.rank != 0:
+            return None
+        for r in range(self.world):
+            self.frame.index_copy_(0, self.all_ids_dev[r], self.gather_list[r][: self.counts[r]])
+        return self.frame
 
 
 class TiledRenderer:
-    """One process per GPU.  Holds the uploaded scene, this rank's pixel list and the device buffers;
-    `render_frame()` = local fw_render into HBM + one gather to rank 0."""
+    """One process per GPU: uploaded scene + this rank's tiles; `render_frame()` = local fw_render into HBM
+    + TileGather.assemble()."""
 
     def __init__(self, scene, renderer, rank=0, world=1, device=0, tile=TILE, dist=None):
         import torch
         from . import _lib
-        self.torch, self.dist = torch, dist
-        self.rank, self.world, self.renderer = rank, world, renderer
+        self.torch, self.renderer = torch, renderer
         s = renderer.settings
-        self.width, self.height = s["width"], s["height"]
-        self.ids = np.ascontiguousarray(tile_pixel_ids(self.width, self.height, rank, world, tile))
-        self.n_local = int(self.ids.shape[0])
-        self.n_max = max_tile_pixels(self.width, self.height, world, tile) if world > 1 else self.n_local
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
+        self.tg = TileGather(s["width"], s["height"], rank, world, self.dev, dist, tile)
         self.scene = _lib.DeviceScene(scene if hasattr(scene, "ptr") else scene.to_desc(), device)
-        self.rgb8 = torch.zeros((self.n_max, 3), dtype=torch.uint8, device=self.dev)
-        self.ids_dev = torch.from_numpy(self.ids.astype(np.int64)).to(self.dev)
-        if world > 1:
-            all_ids = [tile_pixel_ids(self.width, self.height, r, world, tile) for r in range(world)]
-            self.all_counts = [int(a.shape[0]) for a in all_ids]
-            if rank == 0:
-                self.all_ids_dev = [torch.from_numpy(a.astype(np.int64)).to(self.dev) for a in all_ids]
-                self.gather_list = [torch.zeros((self.n_max, 3), dtype=torch.uint8, device=self.dev) for _ in range(world)]
-        self.frame = torch.zeros((self.width * self.height, 3), dtype=torch.uint8, device=self.dev) if rank == 0 else None
+        self.world = world
         self.last_stats = None
+        self.frame = None
 
     def render_frame(self):
         """Returns the (H*W,3) uint8 device tensor on rank 0 (None elsewhere)."""
-        torch = self.torch
-        stream = torch.cuda.current_stream(self.dev).cuda_stream
-        pix = None if (self.world == 1) else self.ids
-        self.last_stats = self.scene.render(self.renderer, pixel_ids=pix,
-                                            out_device_ptrs=(self.rgb8.data_ptr(), None, None), stream=stream)
-        if self.world == 1:
-            self.frame = self.rgb8[: self.n_local]
-            return self.frame
-        # the only collective: finished tiles -> rank 0 (payload <= W*H*3 bytes in total)
-        self.dist.gather(self.rgb8, self.gather_list if self.rank == 0 else None, dst=0)
-        if self.rank == 0:
-            for r in range(self.world):
-                self.frame.index_copy_(0, self.all_ids_dev[r], self.gather_list[r][: self.all_counts[r]])
-            return self.frame
-        return None
+        stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+        self.last_stats = self.scene.render(self.renderer, pixel_ids=self.tg.ids,
+                                            out_device_ptrs=(self.tg.local.data_ptr(), None, None), stream=stream)
+        self.frame = self.tg.assemble()
+        return self.frame
 
     def close(self):
         self.scene.close()
