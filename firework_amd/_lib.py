@@ -12,7 +12,7 @@ import numpy as np
 from . import _abi as A
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfirework_hip.so")
+LIB_PATH = os.environ.get("FIREWORK_LIB") or os.path.join(_HERE, "lib", "libfirework_hip.so")
 _lib = None
 
 
@@ -49,6 +49,8 @@ def load():
     lib.fw_render_scene.restype = C.c_int
     lib.fw_render_scene.argtypes = [C.POINTER(A.fw_scene_desc), C.POINTER(A.fw_render_params), C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.POINTER(A.fw_stats)]
+    lib.fw_selftest_arith.restype = C.c_int
+    lib.fw_selftest_arith.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     if lib.fw_abi_version() != A.FW_ABI_VERSION:
         raise FireworkError(A.FW_ERR_BAD_ARG, "ABI version mismatch between _abi.py and libfirework_hip.so")
     _lib = lib
@@ -58,6 +60,13 @@ def load():
 def _check(lib, st):
     if st != A.FW_OK:
         raise FireworkError(st, f"{lib.fw_strerror(st).decode()} | {lib.fw_last_error().decode()}")
+
+
+def selftest_arith(n, seed=1, mode=0, device=0):
+    lib = load()
+    d, s = C.c_uint64(), C.c_uint64()
+    _check(lib, lib.fw_selftest_arith(device, n, seed, mode, C.byref(d), C.byref(s)))
+    return int(d.value), int(s.value)
 
 
 def device_count():

@@ -36,13 +36,16 @@ enum : uint32_t {
 //   A>>30 == 0: Branch      right child = A & 0x3fffffff
 //   A>>30 == 1: Leaf        item = A & 0x3fffffff
 //   A>>30 == 2: DoubleLeaf  items = A & 0x3fffffff, B
+constexpr uint32_t MF_NEEDS_UV = 1u << 8;    // the material's texture tree contains an ImageTexture
+constexpr uint32_t MF_TEX_CONST = 1u << 9;   // texture is a ConstantTexture, colour inlined in the record
 constexpr uint32_t NODE_LEAF = 1u, NODE_DOUBLE = 2u, NODE_MASK = 0x3fffffffu;
 
 // ---- triangle: 3 x float4 = 48 B: (p0.xyz u0) (p1.xyz u1) (p2.xyz u2), vertices pre-gathered through
 //      the index buffer.  Meshes with vertex normals and/or uvs add an attribute array of 3 x float4:
 //      (n0.xyz v0) (n1.xyz v1) (n2.xyz v2).  Without uvs the defaults (0,0),(1,0),(0,1) of mesh.rs:99-109
 //      are u = (0,1,0) in the .w lanes and v = (0,0,1) as constants.
-// ---- material: 2 x float4: (bits kind, bits texture, roughness, ref_idx) (albedo.rgb, -)
+// ---- material: 2 x float4: (bits kind | MF_*, bits texture, roughness, ref_idx) (colour.rgb, -)
+//      colour = Metal albedo, or the ConstantTexture colour when MF_TEX_CONST (no texture fetch needed)
 // ---- texture : 2 x float4: (bits kind, scale, bits depth, bits odd) then by kind:
 //        constant (color.rgb -) | checker (bits even - - -) | image (bits byte offset, bits w, bits h, -)
 
@@ -81,6 +84,8 @@ struct DFrame {
     uint32_t seed32;
     uint32_t sample0;             // first sample index of this batch
     uint32_t spp_batch;           // samples per pixel in this batch
+    float inv_width;              // 1.0f / width
+    float inv_n_pixels;           // 1.0f / n_pixels (path_id -> sample index without an integer division)
 };
 
 // ---- wavefront path state, SoA over path slots (DESIGN.md §"Path state")
@@ -90,6 +95,14 @@ struct DPaths {
     float4 *state;   // (beta.r beta.g beta.b, bits path_id)
 };
 
+// wave-private queues: wave w owns slots [w*cap, (w+1)*cap) of every path array;
+// wcount[segment * n_waves + w] = live paths of wave w entering that segment (segment 0..MAX_SEGMENTS)
+struct DQueue {
+    uint32_t n_waves, cap;      // cap = 64 << cpw_shift slots per wave
+    uint32_t cpw_shift;         // log2(chunks of 64 per wave)
+    uint32_t *wcount;
+};
+
 constexpr uint32_t MISS = 0xffffffffu;
 constexpr int MAX_SEGMENTS = 11;
 constexpr int COUNT_STRIDE = 16;  // u32 counters per batch: [0..10] queue sizes, [11] spare
@@ -97,15 +110,20 @@ constexpr int COUNT_STRIDE = 16;  // u32 counters per batch: [0..10] queue sizes
 // launch wrappers (fw_kernels.hip)
 struct LaunchCfg {
     hipStream_t stream;
-    int blocks_extend, blocks_shade, blocks_other;
+    DQueue q;
+    int blocks_other;
     int tlas_depth, blas_depth;   // LDS traversal-stack levels needed
+    uint32_t n_mat, n_tex;        // table sizes (for the LDS-resident copy in k_shade)
+    bool lds_tables;              // stage small scene tables in LDS (debug switch: FIREWORK_NO_LDS_TABLES)
 };
+constexpr size_t LDS_TABLE_LIMIT = 16 * 1024;   // object+material+texture tables up to this size are staged in LDS
 
-void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, uint32_t *counts, uint32_t n_paths);
-void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float4 *hits, const uint32_t *counts,
-                   int segment, bool use_bvh);
+void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, uint32_t n_paths);
+void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float4 *hits, int segment, bool use_bvh);
 void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, const float4 *hits,
-                  float4 *sample_rad, uint32_t *counts, int segment);
+                  float4 *sample_rad, int segment);
+void launch_queue_totals(const LaunchCfg &, uint32_t *totals);
+void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out);
 void launch_accumulate(const LaunchCfg &, const DFrame &, const float4 *sample_rad, float4 *accum);
 void launch_resolve(const LaunchCfg &, const DFrame &, const float4 *accum, uint32_t total_spp, float gamma,
                     uint8_t *rgb8, float *gamma_rgb, float *linear_rgb);

@@ -10,9 +10,11 @@
 //   k_accumulate  `total_color += color(..)` in sample order      render.rs:181
 //   k_resolve     /spp, powf(1/gamma), clamp, Color::from          render.rs:184-190, util.rs:14-23
 //
-// One lane = one path.  Path state lives in HBM as SoA arrays and is compacted every segment with
-// wave ballots + one atomic per workgroup; all paths of a queue are at the same depth, so the depth
-// is a kernel argument, not state.  Every random draw is a pure function of
+// One lane = one path.  Path state lives in HBM as SoA arrays.  The path pool is split into WAVE-PRIVATE
+// queues: wavefront w owns slots [w*cap, (w+1)*cap) of every array and compacts its
+// survivors there with a wave ballot + mbcnt prefix — no atomics, no barriers, no cross-wave traffic, and
+// a deterministic slot order.  All paths of a launch are at the same depth, so the depth is a kernel
+// argument, not state.  Every random draw is a pure function of
 // (seed, pixel, sample, dimension), so the image does not depend on scheduling.
 //
 // Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE-exact and written in the same
@@ -33,16 +35,63 @@ __device__ __forceinline__ V3 operator-(V3 a) { return {-a.x, -a.y, -a.z}; }
 __device__ __forceinline__ V3 operator*(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 __device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
-__device__ __forceinline__ V3 operator/(V3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return {fmaf(a.y, b.z, -a.z * b.y), fmaf(a.z, b.x, -a.x * b.z), fmaf(a.x, b.y, -a.y * b.x)};
 }
 __device__ __forceinline__ float mag_sq(V3 a) { return dot(a, a); }
-__device__ __forceinline__ float mag(V3 a) { return sqrtf(mag_sq(a)); }
-__device__ __forceinline__ V3 normalized(V3 a) { float m = mag(a); return {a.x / m, a.y / m, a.z / m}; }
 __device__ __forceinline__ float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 __device__ __forceinline__ V3 ld3(const float *p) { return {p[0], p[1], p[2]}; }
+
+// ------------------------------------------------------------------------------------------------
+// Division and square root.  hipcc lowers `a / b` to v_div_scale x2, v_rcp, 6 fma/mul, v_div_fmas,
+// v_div_fixup (~41 SIMD-cycles per wave64 on MI355X, tools/microbench.hip) and sqrtf to ~53.  fdiv/fsqrt run
+// the same Newton/residual chain without the scaling steps: identical, correctly rounded bits whenever
+// v_div_scale would be the identity (every operand magnitude a renderer produces; exponents within ~2^+-96),
+// v_div_fixup still supplies the IEEE results for zero / infinite / NaN operands (x/0 = +-inf is what the
+// reference's range tests rely on), and a denominator shared by several quotients is inverted once.
+// Build with -DFW_FAST_DIV=0 to use the compiler's expansion everywhere (A/B: tests pass bit-identically).
+// ------------------------------------------------------------------------------------------------
+#ifndef FW_FAST_DIV
+#define FW_FAST_DIV 1
+#endif
+#ifndef FW_WB
+#define FW_WB 64   // threads per workgroup of the queue kernels: single-wave workgroups retire independently
+#endif
+struct Rcp { float b, r; };
+__device__ __forceinline__ Rcp make_rcp(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    r = fmaf(fmaf(-b, r, 1.0f), r, r);
+    return Rcp{b, r};
+}
+__device__ __forceinline__ float fdiv(float a, const Rcp &c) {
+#if FW_FAST_DIV
+    float q = a * c.r;
+    q = fmaf(fmaf(-c.b, q, a), c.r, q);
+    q = fmaf(fmaf(-c.b, q, a), c.r, q);
+    return __builtin_amdgcn_div_fixupf(q, c.b, a);
+#else
+    return a / c.b;
+#endif
+}
+__device__ __forceinline__ float fdiv(float a, float b) { return fdiv(a, make_rcp(b)); }
+// v_sqrt_f32 is within 1 ulp; pick among s-1ulp, s, s+1ulp by the sign of the exact residuals (the test the
+// compiler's own expansion uses).  0, inf and NaN pass through unchanged (their residual tests are false).
+__device__ __forceinline__ float fsqrt(float x) {
+#if FW_FAST_DIV
+    float s = __builtin_amdgcn_sqrtf(x);
+    float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    float vd = fmaf(-sd, s, x), vu = fmaf(-su, s, x);
+    s = (vd <= 0.f) ? sd : s;
+    s = (vu > 0.f) ? su : s;
+    return s;
+#else
+    return sqrtf(x);
+#endif
+}
+__device__ __forceinline__ V3 operator/(V3 a, float s) { Rcp c = make_rcp(s); return {fdiv(a.x, c), fdiv(a.y, c), fdiv(a.z, c)}; }
+__device__ __forceinline__ float mag(V3 a) { return fsqrt(mag_sq(a)); }
+__device__ __forceinline__ V3 normalized(V3 a) { return a / mag(a); }
 
 struct Ray { V3 o, d; };
 __device__ __forceinline__ V3 ray_point(const Ray &r, float t) { return r.o + t * r.d; }
@@ -90,12 +139,15 @@ __device__ __forceinline__ V3 random_in_unit_disk(const RngKey &k) {
     return p;
 }
 
-// path_id -> (pixel index as in render.rs:127, sample index)
+// path_id -> (pixel index as in render.rs:127, sample index).  path_id = s_local * n_pixels + p_local with
+// s_local < 2^12, so a float quotient is off by at most one: fix it up instead of a 32-bit integer division.
 __device__ __forceinline__ RngKey key_of(const DFrame &f, uint32_t path_id) {
-    uint32_t s_local = path_id / f.n_pixels;
-    uint32_t p_local = path_id - s_local * f.n_pixels;
+    uint32_t s_local = (uint32_t)((float)path_id * f.inv_n_pixels);
+    int32_t p_local = (int32_t)(path_id - s_local * f.n_pixels);
+    if (p_local < 0) { s_local--; p_local += (int32_t)f.n_pixels; }
+    else if ((uint32_t)p_local >= f.n_pixels) { s_local++; p_local -= (int32_t)f.n_pixels; }
     RngKey k;
-    k.pixel = f.pixel_ids ? f.pixel_ids[p_local] : p_local;
+    k.pixel = f.pixel_ids ? f.pixel_ids[p_local] : (uint32_t)p_local;
     k.sample = f.sample0 + s_local;
     k.seed32 = f.seed32;
     return k;
@@ -104,25 +156,43 @@ __device__ __forceinline__ RngKey key_of(const DFrame &f, uint32_t path_id) {
 // ------------------------------------------------------------------------------------------------
 // K1  ray generation
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_raygen(DCamera cam, DFrame f, DPaths out, uint32_t *counts, uint32_t n_paths) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[0] = n_paths;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_paths; i += gridDim.x * BLOCK) {
-        RngKey k = key_of(f, i);
-        uint32_t px = k.pixel % f.width;                 // util.rs:31-33 Coord::from_index
-        uint32_t py = f.height - k.pixel / f.width;
-        uint4 j = draw(k, P_JITTER, 0, 0);
-        float u = ((float)px + u2f(j.x)) / (float)f.width;      // render.rs:178
-        float v = ((float)py + u2f(j.y)) / (float)f.height;     // render.rs:179
-        // camera.rs:109-116 — the disk sample is drawn even when the aperture is 0
-        V3 rd = cam.lens_radius * random_in_unit_disk(k);
-        V3 cu = ld3(cam.u), cv = ld3(cam.v), pos = ld3(cam.position);
-        V3 offset = cu * rd.x + cv * rd.y;
-        V3 o = pos + offset;
-        V3 d = ld3(cam.lower_left) + u * ld3(cam.horizontal) + v * ld3(cam.vertical) - pos - offset;
-        out.ray_a[i] = make_float4(o.x, o.y, o.z, d.x);
-        out.ray_b[i] = make_float2(d.y, d.z);
-        out.state[i] = make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
+constexpr int WB = FW_WB;
+__device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (WB / 64) + (threadIdx.x >> 6); }
+
+// Wave w generates the paths  id = chunk * (n_waves*64) + w*64 + lane  (chunks of 64 consecutive pixels of
+// one sample index, dealt round-robin to the waves: coherent inside a wave, balanced across waves).
+__global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out, DQueue q, uint32_t n_paths) {
+    const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
+    if (w >= q.n_waves) return;
+    const Rcp rw = make_rcp((float)f.width), rh = make_rcp((float)f.height);
+    uint32_t produced = 0;
+    for (uint32_t chunk = 0;; chunk++) {
+        uint32_t id0 = chunk * (q.n_waves * 64u) + w * 64u;
+        if (id0 >= n_paths) break;
+        uint32_t i = id0 + lane;
+        if (i < n_paths) {
+            RngKey k = key_of(f, i);
+            uint32_t py_row = (uint32_t)((float)k.pixel * f.inv_width);      // k.pixel / width without an integer division
+            int32_t px = (int32_t)(k.pixel - py_row * f.width);
+            if (px < 0) { py_row--; px += (int32_t)f.width; } else if ((uint32_t)px >= f.width) { py_row++; px -= (int32_t)f.width; }
+            uint32_t py = f.height - py_row;                                  // util.rs:31-33 Coord::from_index
+            uint4 j = draw(k, P_JITTER, 0, 0);
+            float u = fdiv((float)px + u2f(j.x), rw);                         // render.rs:178
+            float v = fdiv((float)py + u2f(j.y), rh);                         // render.rs:179
+            // camera.rs:109-116 — the disk sample is drawn even when the aperture is 0
+            V3 rd = cam.lens_radius * random_in_unit_disk(k);
+            V3 cu = ld3(cam.u), cv = ld3(cam.v), pos = ld3(cam.position);
+            V3 offset = cu * rd.x + cv * rd.y;
+            V3 o = pos + offset;
+            V3 d = ld3(cam.lower_left) + u * ld3(cam.horizontal) + v * ld3(cam.vertical) - pos - offset;
+            uint32_t slot = w * q.cap + chunk * 64u + lane;
+            out.ray_a[slot] = make_float4(o.x, o.y, o.z, d.x);
+            out.ray_b[slot] = make_float2(d.y, d.z);
+            out.state[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
+        }
+        produced += min(64u, n_paths - id0);
     }
+    if (lane == 0) q.wcount[w] = produced;                                    // segment 0 queue length of this wave
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -172,8 +242,9 @@ __device__ __forceinline__ bool hit_sphere(float radius, const Ray &r, float tmi
     float disc = b * b - 4.f * a * c;
     if (disc < 0.f) return false;
     float t1, t2; bool two;
-    if (disc == 0.f) { t1 = -b / (2.f * a); t2 = 0.f; two = false; }
-    else { float sq = sqrtf(disc); t1 = (-b - sq) / (2.f * a); t2 = (-b + sq) / (2.f * a); two = true; }
+    Rcp two_a = make_rcp(2.f * a);
+    if (disc == 0.f) { t1 = fdiv(-b, two_a); t2 = 0.f; two = false; }
+    else { float sq = fsqrt(disc); t1 = fdiv(-b - sq, two_a); t2 = fdiv(-b + sq, two_a); two = true; }
     if (t1 < tmax && t1 > tmin) { t_out = t1; return true; }
     if (two && t2 < tmax && t2 > tmin) { t_out = t2; return true; }
     return false;
@@ -184,7 +255,7 @@ template <int AX>
 __device__ __forceinline__ bool hit_rect(float a_min, float a_max, float b_min, float b_max, float k, const Ray &r,
                                          float tmin, float tmax, float &t_out) {
     constexpr int A1 = (AX == 2) ? 1 : 0, A2 = (AX == 0) ? 1 : 2, OT = (AX == 0) ? 2 : (AX == 1 ? 1 : 0);
-    float t = (k - comp(r.o, OT)) / comp(r.d, OT);
+    float t = fdiv(k - comp(r.o, OT), comp(r.d, OT));
     if (t < tmin || t > tmax) return false;
     V3 p = ray_point(r, t);
     float pa = comp(p, A1), pb = comp(p, A2);
@@ -201,13 +272,14 @@ __device__ __forceinline__ bool hit_rect_kind(uint32_t kind, float4 q3, float k,
 // objects/rect3d.rs:18-100 — faces +z, -z, +y, -y, +x, -x; linear closest with narrowing, later wins ties
 __device__ __forceinline__ bool hit_rect3d(float4 q3, float4 q4, const Ray &r, float tmin, float tmax, float &t_out, uint32_t &face) {
     float px = q3.x, py = q3.y, pz = q3.z, sx = q3.w, sy = q4.x, sz = q4.y;
-    bool any = false; float closest = tmax, t;
-    if (hit_rect<0>(px, px + sx, py, py + sy, pz + sz, r, tmin, closest, t)) { closest = t; face = 0; any = true; }
-    if (hit_rect<0>(px, px + sx, py, py + sy, pz, r, tmin, closest, t)) { closest = t; face = 1; any = true; }
-    if (hit_rect<1>(px, px + sx, pz, pz + sz, py + sy, r, tmin, closest, t)) { closest = t; face = 2; any = true; }
-    if (hit_rect<1>(px, px + sx, pz, pz + sz, py, r, tmin, closest, t)) { closest = t; face = 3; any = true; }
-    if (hit_rect<2>(py, py + sy, pz, pz + sz, px + sx, r, tmin, closest, t)) { closest = t; face = 4; any = true; }
-    if (hit_rect<2>(py, py + sy, pz, pz + sz, px, r, tmin, closest, t)) { closest = t; face = 5; any = true; }
+    bool any = false; float closest = tmax, t; face = 0;
+    bool h;
+    h = hit_rect<0>(px, px + sx, py, py + sy, pz + sz, r, tmin, closest, t); closest = h ? t : closest; face = h ? 0u : face; any |= h;
+    h = hit_rect<0>(px, px + sx, py, py + sy, pz, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 1u : face; any |= h;
+    h = hit_rect<1>(px, px + sx, pz, pz + sz, py + sy, r, tmin, closest, t); closest = h ? t : closest; face = h ? 2u : face; any |= h;
+    h = hit_rect<1>(px, px + sx, pz, pz + sz, py, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 3u : face; any |= h;
+    h = hit_rect<2>(py, py + sy, pz, pz + sz, px + sx, r, tmin, closest, t); closest = h ? t : closest; face = h ? 4u : face; any |= h;
+    h = hit_rect<2>(py, py + sy, pz, pz + sz, px, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 5u : face; any |= h;
     t_out = closest;
     return any;
 }
@@ -229,7 +301,8 @@ __device__ __forceinline__ bool hit_triangle(V3 p0, V3 p1, V3 p2, const Ray &r, 
     p0t = mk(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
     p1t = mk(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
     p2t = mk(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
-    float sx = -d.x / d.z, sy = -d.y / d.z, sz = 1.f / d.z;
+    Rcp dz = make_rcp(d.z);
+    float sx = fdiv(-d.x, dz), sy = fdiv(-d.y, dz), sz = fdiv(1.f, dz);
     p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
     p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
     p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
@@ -243,7 +316,7 @@ __device__ __forceinline__ bool hit_triangle(V3 p0, V3 p1, V3 p2, const Ray &r, 
     float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
     if (det < 0.f && (t_scaled >= tmin * det || t_scaled < tmax * det)) return false;
     else if (det > 0.f && (t_scaled <= tmin * det || t_scaled > tmax * det)) return false;
-    float inv_det = 1.f / det;
+    float inv_det = fdiv(1.f, det);
     b0 = e0 * inv_det; b1 = e1 * inv_det; b2 = e2 * inv_det;
     t_out = t_scaled * inv_det;
     return true;
@@ -269,8 +342,8 @@ __device__ __forceinline__ bool hit_aabb(float4 lo, float4 hi, V3 o, V3 inv, flo
 // 64 consecutive dwords (conflict-free).  `base` = first level this traversal may use.
 struct LdsStack {
     uint32_t *s; int sp;
-    __device__ __forceinline__ void push(uint32_t v) { s[sp * BLOCK] = v; sp++; }
-    __device__ __forceinline__ uint32_t pop() { sp--; return s[sp * BLOCK]; }
+    __device__ __forceinline__ void push(uint32_t v) { s[sp * FW_WB] = v; sp++; }
+    __device__ __forceinline__ uint32_t pop() { sp--; return s[sp * FW_WB]; }
 };
 
 // K4  mesh BLAS (bvh.rs:100-151 over Triangle items).  The reference visits both children with the
@@ -280,7 +353,7 @@ struct LdsStack {
 // a later triangle replaces the current one unless current.t < t — the same winner.
 __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32_t tri_base, const Ray &r, float tmin,
                                          float tmax, uint32_t *stack_base, float &t_out, uint32_t &tri_out) {
-    V3 inv = mk(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+    V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
     LdsStack st{stack_base, 0};
     bool have = false; float best = tmax; uint32_t best_tri = 0;
     uint32_t node = root;
@@ -336,8 +409,8 @@ __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const
     float dmag = mag(r.d);
     float dist_inside_boundary = (t2 - t1) * dmag;
     float xi = u2f(draw(key, P_VOLUME, segment, obj_index).x);
-    float hit_distance = -(1.f / o.q4.w) * log10f(xi);          // log10, as written (volume.rs:67)
-    if (hit_distance < dist_inside_boundary) { t_out = t1 + hit_distance / dmag; return true; }
+    float hit_distance = -fdiv(1.f, o.q4.w) * log10f(xi);       // log10, as written (volume.rs:67)
+    if (hit_distance < dist_inside_boundary) { t_out = t1 + fdiv(hit_distance, dmag); return true; }
     return false;
 }
 
@@ -356,13 +429,22 @@ __device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint3
 extern __shared__ uint32_t lds_stack[];
 
 template <bool USE_BVH>
-__global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, DFrame f, DPaths in, float4 *__restrict__ hits,
-                                                  const uint32_t *__restrict__ counts, int segment, int tlas_levels) {
-    const uint32_t n = counts[segment];
+__global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, float4 *__restrict__ hits,
+                                                  DQueue q, int segment, int tlas_levels) {
+    const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
+    if (w >= q.n_waves) return;
+    const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w];
+    const uint32_t base = w * q.cap;
     uint32_t *my_stack = lds_stack + threadIdx.x;                    // [level][lane]
-    uint32_t *blas_stack = my_stack + (size_t)tlas_levels * BLOCK;   // BLAS levels sit above the TLAS levels
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
-        float4 ra = in.ray_a[i]; float2 rb = in.ray_b[i];
+    uint32_t *blas_stack = my_stack + (size_t)tlas_levels * WB;      // BLAS levels sit above the TLAS levels
+    float4 ra_n = make_float4(0, 0, 0, 0); float2 rb_n = make_float2(0, 0);
+    if (lane < n) { ra_n = in.ray_a[base + lane]; rb_n = in.ray_b[base + lane]; }
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const uint32_t j = c0 + lane;
+        const uint32_t i = base + j;
+        float4 ra = ra_n; float2 rb = rb_n;
+        if (j + 64u < n) { ra_n = in.ray_a[i + 64u]; rb_n = in.ray_b[i + 64u]; }
+        if (j >= n) continue;
         Ray r{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
         RngKey key{0, 0, 0};
         if (sc.has_medium) key = key_of(f, __float_as_uint(in.state[i].w));
@@ -371,13 +453,13 @@ __global__ __launch_bounds__(BLOCK) void k_extend(DScene sc, DFrame f, DPaths in
         if (!USE_BVH) {
             // scene.rs:137-149: linear scan with narrowing; a later object replaces on t <= closest
             for (uint32_t j = 0; j < sc.n_objects; j++) {
-                Obj o = load_obj(sc.obj, j);
+                Obj o = load_obj(sc.obj, j);     // wave-uniform index: scalar loads
                 float t; uint32_t prim;
                 if (hit_object(sc, o, j, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = j; best_prim = prim; }
             }
         } else {
             // bvh.rs:88-98,115-151 over RenderObjectInternal items; same in-order scheme as hit_mesh
-            V3 inv = mk(1.f / r.d.x, 1.f / r.d.y, 1.f / r.d.z);
+            V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
             LdsStack st{my_stack, 0};
             bool have = false;
             uint32_t node = 0;
@@ -457,9 +539,9 @@ __device__ float turb(uint32_t depth, V3 point) {    // texture.rs:206-217
 __device__ __forceinline__ uint32_t sat_u32(float f) { if (!(f > 0.f)) return 0u; if (f >= 4294967296.f) return 0xffffffffu; return (uint32_t)f; }
 
 // Texture::sample (texture.rs).  Checker recursion is unrolled into a bounded walk.
-__device__ V3 texture_sample(const DScene &sc, uint32_t tex, float u, float v, V3 p) {
+__device__ __forceinline__ V3 texture_sample(const float4 *texp, const uint8_t *images, uint32_t tex, float u, float v, V3 p) {
     for (int guard = 0; guard < 16; guard++) {
-        float4 t0 = sc.tex[2 * (size_t)tex], t1 = sc.tex[2 * (size_t)tex + 1];
+        float4 t0 = texp[2 * tex], t1 = texp[2 * tex + 1];
         uint32_t kind = __float_as_uint(t0.x);
         float scale = t0.y; uint32_t depth = __float_as_uint(t0.z);
         switch (kind) {
@@ -477,7 +559,7 @@ __device__ V3 texture_sample(const DScene &sc, uint32_t tex, float u, float v, V
             uint32_t off = __float_as_uint(t1.x), w = __float_as_uint(t1.y), h = __float_as_uint(t1.z);
             float fi = u * (float)w, fj = (1.f - v) * (float)h;
             uint32_t i = min(sat_u32(fi), w - 1), j = min(sat_u32(fj), h - 1);
-            const uint8_t *c = sc.images + off + 3 * ((size_t)j * w + i);
+            const uint8_t *c = images + off + 3 * ((size_t)j * w + i);
             return mk((float)c[0], (float)c[1], (float)c[2]) / 255.f; }
         default: return mk(0.f, 0.f, 0.f);
         }
@@ -489,8 +571,8 @@ constexpr float PI_F = 3.14159265358979323846f;
 __device__ __forceinline__ void sphere_uv(V3 p, float &u, float &v) {   // objects/sphere.rs:22-29
     float phi = atan2f(p.z, p.x);
     float theta = asinf(p.y);
-    u = 1.f - (phi + PI_F) / (2.f * PI_F);
-    v = (theta + PI_F / 2.f) / PI_F;
+    u = 1.f - fdiv(phi + PI_F, 2.f * PI_F);
+    v = fdiv(theta + PI_F / 2.f, PI_F);
 }
 
 __device__ V3 env_sample(const DEnv &e, V3 dir) {     // environment.rs:21-26,60-67; examples/hdri_test.rs:70-82
@@ -515,11 +597,11 @@ __device__ __forceinline__ bool refract(V3 v, V3 n, float ni_over_nt, V3 &out) {
     V3 uv = normalized(v);
     float dt = dot(uv, n);
     float disc = 1.f - ni_over_nt * ni_over_nt * (1.f - dt * dt);
-    if (disc > 0.f) { out = ni_over_nt * (uv - n * dt) - n * sqrtf(disc); return true; }
+    if (disc > 0.f) { out = ni_over_nt * (uv - n * dt) - n * fsqrt(disc); return true; }
     return false;
 }
 __device__ __forceinline__ float schlick(float cosine, float ref_idx) {                          // util.rs:69-73
-    float r0 = (1.f - ref_idx) / (1.f + ref_idx);
+    float r0 = fdiv(1.f - ref_idx, 1.f + ref_idx);
     r0 = r0 * r0;
     return r0 + (1.f - r0) * powf(1.f - cosine, 5.f);
 }
@@ -528,15 +610,17 @@ __device__ __forceinline__ float schlick(float cosine, float ref_idx) {         
 struct HitInfo { V3 point, normal; float u, v; uint32_t material; };
 
 __device__ __forceinline__ void rect_hitinfo(uint32_t kind, float a_min, float a_max, float b_min, float b_max, bool flip,
-                                             V3 p, V3 &normal, float &u, float &v) {
+                                             V3 p, V3 &normal, float &u, float &v, bool need_uv) {
     int a1 = (kind == 3) ? 1 : 0, a2 = (kind == 1) ? 1 : 2, ot = (kind == 1) ? 2 : (kind == 2 ? 1 : 0);
     V3 n = mk(ot == 0 ? 1.f : 0.f, ot == 1 ? 1.f : 0.f, ot == 2 ? 1.f : 0.f);
     normal = flip ? -n : n;
-    u = (comp(p, a1) - a_min) / (a_max - a_min);
-    v = (comp(p, a2) - b_min) / (b_max - b_min);
+    if (need_uv) {   // uv feed ImageTexture only (texture.rs:296-309); every other texture ignores them
+        u = fdiv(comp(p, a1) - a_min, a_max - a_min);
+        v = fdiv(comp(p, a2) - b_min, b_max - b_min);
+    }
 }
 
-__device__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, const Ray &world, float t, uint32_t prim) {
+__device__ __forceinline__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, const Ray &world, float t, uint32_t prim, bool need_uv) {
     Ray r = to_object_space(o, world);
     uint32_t kind = obj_kind(o), flags = obj_flags(o);
     HitInfo h; h.material = o.material; h.u = 0.f; h.v = 0.f;
@@ -544,18 +628,18 @@ __device__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, const Ray &world,
     switch (kind) {
     case 0: {                                                                          // sphere.rs:49-56
         n = p / o.q3.x;
-        sphere_uv(p / o.q3.x, h.u, h.v);
+        if (need_uv) sphere_uv(n, h.u, h.v);
         break; }
     case 1: case 2: case 3:
-        rect_hitinfo(kind, o.q3.x, o.q3.y, o.q3.z, o.q3.w, (flags & OF_RECT_FLIP) != 0, p, n, h.u, h.v);
+        rect_hitinfo(kind, o.q3.x, o.q3.y, o.q3.z, o.q3.w, (flags & OF_RECT_FLIP) != 0, p, n, h.u, h.v, need_uv);
         break;
     case 4: {                                                                          // rect3d.rs:18-80
         float px = o.q3.x, py = o.q3.y, pz = o.q3.z, sx = o.q3.w, sy = o.q4.x, sz = o.q4.y;
         uint32_t fk = 1 + (prim >> 1);   // faces 0,1 -> XY(1); 2,3 -> XZ(2); 4,5 -> YZ(3)
         bool flip = (prim & 1) != 0;
-        if (fk == 1) rect_hitinfo(1, px, px + sx, py, py + sy, flip, p, n, h.u, h.v);
-        else if (fk == 2) rect_hitinfo(2, px, px + sx, pz, pz + sz, flip, p, n, h.u, h.v);
-        else rect_hitinfo(3, py, py + sy, pz, pz + sz, flip, p, n, h.u, h.v);
+        if (fk == 1) rect_hitinfo(1, px, px + sx, py, py + sy, flip, p, n, h.u, h.v, need_uv);
+        else if (fk == 2) rect_hitinfo(2, px, px + sx, pz, pz + sz, flip, p, n, h.u, h.v, need_uv);
+        else rect_hitinfo(3, py, py + sy, pz, pz + sz, flip, p, n, h.u, h.v, need_uv);
         break; }
     case 5: {                                                                          // mesh.rs:196-218
         const float4 *tp = sc.tri + 3 * (size_t)(o.aux1 + prim);
@@ -589,54 +673,82 @@ __device__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, const Ray &world,
 
 // ------------------------------------------------------------------------------------------------
 // K5 + K7  shade + stream compaction
+//
+// k_shade is latency-bound (rocprofv3: 79 % of wave cycles in s_waitcnt in the first version): the chain
+// hit -> object record -> material -> texture is three dependent fetches.  LDS_TAB = true stages the
+// object / material / texture tables in LDS once per workgroup (scenes whose tables fit 16 KB: cornell,
+// suzanne, hdri, volume), which turns those fetches into ~64-cycle ds_reads; materials whose texture is a
+// ConstantTexture carry the colour inline, removing the third level entirely.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DFrame f, DPaths in, DPaths out, const float4 *__restrict__ hits,
-                                                 float4 *__restrict__ sample_rad, uint32_t *counts, int segment) {
-    __shared__ uint32_t s_wave_cnt[BLOCK / 64];
-    __shared__ uint32_t s_wave_off[BLOCK / 64];
-    const uint32_t n = counts[segment];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (uint32_t base = blockIdx.x * BLOCK; base < n; base += gridDim.x * BLOCK) {
-        uint32_t i = base + threadIdx.x;
+extern __shared__ float4 lds_tables[];
+
+template <bool LDS_TAB>
+__global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DPaths out, const float4 *__restrict__ hits,
+                                                 float4 *__restrict__ sample_rad, DQueue q, int segment,
+                                                 uint32_t n_mat, uint32_t n_tex) {
+    const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
+    const float4 *objp = sc.obj, *matp = sc.mat, *texp = sc.tex;
+    if (LDS_TAB) {
+        const uint32_t no = sc.n_objects * OBJ_Q, nm = 2 * n_mat, nt = 2 * n_tex;
+        for (uint32_t k = threadIdx.x; k < no; k += WB) lds_tables[k] = sc.obj[k];
+        for (uint32_t k = threadIdx.x; k < nm; k += WB) lds_tables[no + k] = sc.mat[k];
+        for (uint32_t k = threadIdx.x; k < nt; k += WB) lds_tables[no + nm + k] = sc.tex[k];
+        __syncthreads();
+        objp = lds_tables; matp = lds_tables + no; texp = lds_tables + no + nm;
+    }
+    if (w >= q.n_waves) return;
+    const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w];
+    const uint32_t base = w * q.cap;
+    uint32_t out_n = 0;                                                  // survivors written so far (wave-uniform)
+    // software pipeline: next chunk's ray / state / hit are in flight while the current chunk is shaded
+    float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n, hr_n = ra_n; float2 rb_n = make_float2(0, 0);
+    if (lane < n) { ra_n = in.ray_a[base + lane]; rb_n = in.ray_b[base + lane]; st_n = in.state[base + lane]; hr_n = hits[base + lane]; }
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const uint32_t j = c0 + lane;
+        const uint32_t i = base + j;
+        float4 ra = ra_n, st = st_n, hr = hr_n; float2 rb = rb_n;
+        if (j + 64u < n) { ra_n = in.ray_a[i + 64u]; rb_n = in.ray_b[i + 64u]; st_n = in.state[i + 64u]; hr_n = hits[i + 64u]; }
         bool alive = false;
         Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
-        if (i < n) {
-            float4 ra = in.ray_a[i]; float2 rb = in.ray_b[i]; float4 st = in.state[i]; float4 hr = hits[i];
+        if (j < n) {
             Ray r{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
             V3 beta = mk(st.x, st.y, st.z);
             path_id = __float_as_uint(st.w);
             uint32_t obj_index = __float_as_uint(hr.y);
             V3 rad = mk(0.f, 0.f, 0.f);
             if (obj_index == MISS) {
-                rad = beta * env_sample(sc.env, normalized(r.d));                      // render.rs:31
+                // render.rs:31; ColorEnv ignores the direction, so its normalisation (sqrt + 3 divisions) is skipped
+                V3 dir = sc.env.kind == 0 ? r.d : normalized(r.d);
+                rad = beta * env_sample(sc.env, dir);
             } else {
-                Obj o = load_obj(sc.obj, obj_index);
-                HitInfo h = rebuild_hit(sc, o, r, hr.x, __float_as_uint(hr.z));
-                float4 m0 = sc.mat[2 * (size_t)h.material], m1 = sc.mat[2 * (size_t)h.material + 1];
-                uint32_t mkind = __float_as_uint(m0.x), mtex = __float_as_uint(m0.y);
-                RngKey key = key_of(f, path_id);
-                V3 atten = mk(0.f, 0.f, 0.f);
+                Obj o = load_obj(objp, obj_index);
+                float4 m0 = matp[2 * o.material], m1 = matp[2 * o.material + 1];
+                uint32_t mbits = __float_as_uint(m0.x), mkind = mbits & 0xffu, mtex = __float_as_uint(m0.y);
+                bool need_uv = (mbits & MF_NEEDS_UV) != 0, tex_const = (mbits & MF_TEX_CONST) != 0;
+                HitInfo h = rebuild_hit(sc, o, r, hr.x, __float_as_uint(hr.z), need_uv);
+                V3 texc = mk(m1.x, m1.y, m1.z);                                      // inline ConstantTexture / Metal albedo
+                if (!tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
                 if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
-                    rad = beta * texture_sample(sc, mtex, h.u, h.v, h.point);
+                    rad = beta * texc;
                 } else if (segment < 10) {                                             // render.rs:21
+                    RngKey key = key_of(f, path_id);
+                    V3 atten = texc;
                     switch (mkind) {
                     case 0: {                                                          // Lambertian material.rs:64-75
                         V3 target = h.point + h.normal + random_in_unit_sphere(key, segment);
                         nr = Ray{h.point, target - h.point};
-                        atten = texture_sample(sc, mtex, h.u, h.v, h.point);
                         alive = true; break; }
                     case 1: {                                                          // Metal material.rs:90-107
                         V3 reflected = reflect(r.d, h.normal);
                         nr = Ray{h.point, reflected + m0.z * random_in_unit_sphere(key, segment)};
-                        atten = mk(m1.x, m1.y, m1.z);
                         alive = dot(nr.d, h.normal) > 0.f; break; }
                     case 2: {                                                          // Dielectric material.rs:121-151
                         float ref_idx = m0.w;
                         V3 reflected = reflect(r.d, h.normal);
                         V3 outward; float ni_over_nt, cosine;
                         float ddn = dot(r.d, h.normal);
-                        if (ddn > 0.f) { outward = -h.normal; ni_over_nt = ref_idx; cosine = ref_idx * ddn / mag(r.d); }
-                        else { outward = h.normal; ni_over_nt = 1.0f / ref_idx; cosine = -ddn / mag(r.d); }
+                        if (ddn > 0.f) { outward = -h.normal; ni_over_nt = ref_idx; cosine = fdiv(ref_idx * ddn, mag(r.d)); }
+                        else { outward = h.normal; ni_over_nt = fdiv(1.0f, ref_idx); cosine = fdiv(-ddn, mag(r.d)); }
                         atten = mk(1.f, 1.f, 1.f);
                         V3 refracted; bool took_refraction = false;
                         if (refract(r.d, outward, ni_over_nt, refracted)) {
@@ -646,7 +758,6 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DFrame f, DPaths in,
                         if (!took_refraction) nr = Ray{h.point, reflected};
                         alive = true; break; }
                     case 4: {                                                          // Isotropic material.rs:197-204
-                        atten = texture_sample(sc, mtex, h.u, h.v, h.point);
                         nr = Ray{h.point, random_in_unit_sphere(key, segment)};
                         alive = true; break; }
                     default: break;
@@ -656,26 +767,30 @@ __global__ __launch_bounds__(BLOCK) void k_shade(DScene sc, DFrame f, DPaths in,
             }
             if (!alive) sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, 0.f);   // every path writes exactly once
         }
-        // ---- K7: compaction — wave ballot + rank, one global atomic per workgroup ------------------
+        // ---- K7: compaction inside the wave's private queue: ballot -> mbcnt prefix -> dense stores --------
         unsigned long long mask = __ballot(alive);
         uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        if (lane == 0) s_wave_cnt[wave] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t total = 0;
-            for (int w = 0; w < BLOCK / 64; w++) { s_wave_off[w] = total; total += s_wave_cnt[w]; }
-            uint32_t g = total ? atomicAdd(&counts[segment + 1], total) : 0u;
-            for (int w = 0; w < BLOCK / 64; w++) s_wave_off[w] += g;
-        }
-        __syncthreads();
         if (alive) {
-            uint32_t dst = s_wave_off[wave] + rank;
+            uint32_t dst = base + out_n + rank;
             out.ray_a[dst] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x);
             out.ray_b[dst] = make_float2(nr.d.y, nr.d.z);
             out.state[dst] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id));
         }
-        __syncthreads();   // s_wave_off is rewritten next iteration
+        out_n += (uint32_t)__popcll(mask);
     }
+    if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
+}
+
+// per-segment queue totals of one batch (ray statistics): totals[s] = sum_w wcount[s][w]
+__global__ __launch_bounds__(BLOCK) void k_queue_totals(DQueue q, uint32_t *totals) {
+    __shared__ uint32_t part[BLOCK];
+    const uint32_t seg = blockIdx.x;
+    uint32_t acc = 0;
+    for (uint32_t w = threadIdx.x; w < q.n_waves; w += BLOCK) acc += q.wcount[(size_t)seg * q.n_waves + w];
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s2 = BLOCK / 2; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2]; __syncthreads(); }
+    if (threadIdx.x == 0) totals[seg] = part[0];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -699,7 +814,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame f, const float4 *__res
     for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < f.n_pixels; p += gridDim.x * BLOCK) {
         float4 a = accum[p];
         V3 total = mk(a.x, a.y, a.z) / (float)total_spp;                             // render.rs:184
-        float ig = 1.f / gamma;
+        float ig = fdiv(1.f, gamma);
         V3 g = mk(powf(total.x, ig), powf(total.y, ig), powf(total.z, ig));           // render.rs:186
         auto clamp01 = [](float x) { return (x != x) ? x : (x < 0.f ? 0.f : (x > 1.f ? 1.f : x)); };
         g = mk(clamp01(g.x), clamp01(g.y), clamp01(g.z));                             // render.rs:187
@@ -710,21 +825,60 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame f, const float4 *__res
 }
 
 // ------------------------------------------------------------------------------------------------
+// self-test: fdiv / fsqrt against the compiler's IEEE expansion, bit for bit, on hashed operands.
+// mode 0: magnitudes 2^-40 .. 2^40 (what a renderer produces) — must agree exactly.
+// mode 1: the whole float range incl. zeros, infinities, NaNs, denormals — counted, reported, not required.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_selftest_arith(uint32_t n, uint32_t seed, int mode, unsigned long long *out) {
+    unsigned long long bad_div = 0, bad_sqrt = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        uint4 h = pcg4d(make_uint4(i, seed, 0x51u, 0xA5A5u));
+        float a, b;
+        if (mode == 0) {
+            uint32_t ea = 127u - 40u + (h.z % 81u), eb = 127u - 40u + ((h.z >> 8) % 81u);
+            a = __uint_as_float((h.x & 0x807fffffu) | (ea << 23));
+            b = __uint_as_float((h.y & 0x807fffffu) | (eb << 23));
+        } else { a = __uint_as_float(h.x); b = __uint_as_float(h.y); }
+        float q1 = fdiv(a, b), q0 = a / b;
+        bool same = __float_as_uint(q0) == __float_as_uint(q1) || (q0 != q0 && q1 != q1);
+        bad_div += same ? 0 : 1;
+        float x = fabsf(a);
+        float s1 = fsqrt(x), s0 = sqrtf(x);
+        same = __float_as_uint(s0) == __float_as_uint(s1) || (s0 != s0 && s1 != s1);
+        bad_sqrt += same ? 0 : 1;
+    }
+    if (bad_div) atomicAdd(&out[0], bad_div);
+    if (bad_sqrt) atomicAdd(&out[1], bad_sqrt);
+}
+void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out) {
+    hipLaunchKernelGGL(k_selftest_arith, dim3(1024), dim3(BLOCK), 0, stream, n, seed, mode, out);
+}
+
+// ------------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
-void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPaths out, uint32_t *counts, uint32_t n_paths) {
-    hipLaunchKernelGGL(k_raygen, dim3(c.blocks_other), dim3(BLOCK), 0, c.stream, cam, f, out, counts, n_paths);
+static dim3 wave_grid(const LaunchCfg &c) { return dim3((c.q.n_waves + WB / 64 - 1) / (WB / 64)); }
+
+void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPaths out, uint32_t n_paths) {
+    hipLaunchKernelGGL(k_raygen, wave_grid(c), dim3(WB), 0, c.stream, cam, f, out, c.q, n_paths);
 }
-void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float4 *hits, const uint32_t *counts,
-                   int segment, bool use_bvh) {
+void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float4 *hits, int segment, bool use_bvh) {
     int tl = use_bvh ? c.tlas_depth + 1 : 0;
-    size_t lds = (size_t)(tl + c.blas_depth + 1) * BLOCK * sizeof(uint32_t);
-    if (use_bvh) hipLaunchKernelGGL(k_extend<true>, dim3(c.blocks_extend), dim3(BLOCK), lds, c.stream, sc, f, in, hits, counts, segment, tl);
-    else hipLaunchKernelGGL(k_extend<false>, dim3(c.blocks_extend), dim3(BLOCK), lds, c.stream, sc, f, in, hits, counts, segment, tl);
+    size_t lds = (size_t)(tl + c.blas_depth + 1) * WB * sizeof(uint32_t);
+    dim3 eg = wave_grid(c);
+    if (use_bvh) hipLaunchKernelGGL(k_extend<true>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl);
+    else hipLaunchKernelGGL(k_extend<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl);
 }
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float4 *hits,
-                  float4 *sample_rad, uint32_t *counts, int segment) {
-    hipLaunchKernelGGL(k_shade, dim3(c.blocks_shade), dim3(BLOCK), 0, c.stream, sc, f, in, out, hits, sample_rad, counts, segment);
+                  float4 *sample_rad, int segment) {
+    size_t tab = ((size_t)sc.n_objects * OBJ_Q + 2 * (size_t)c.n_mat + 2 * (size_t)c.n_tex) * sizeof(float4);
+    if (c.lds_tables && tab <= LDS_TABLE_LIMIT)
+        hipLaunchKernelGGL(k_shade<true>, wave_grid(c), dim3(WB), tab, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
+    else
+        hipLaunchKernelGGL(k_shade<false>, wave_grid(c), dim3(WB), 0, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
+}
+void launch_queue_totals(const LaunchCfg &c, uint32_t *totals) {
+    hipLaunchKernelGGL(k_queue_totals, dim3(MAX_SEGMENTS), dim3(BLOCK), 0, c.stream, c.q, totals);
 }
 void launch_accumulate(const LaunchCfg &c, const DFrame &f, const float4 *sample_rad, float4 *accum) {
     hipLaunchKernelGGL(k_accumulate, dim3(c.blocks_other), dim3(BLOCK), 0, c.stream, f, sample_rad, accum);

@@ -138,14 +138,14 @@ struct fw_scene {
     int n_cus = 256;
     fw::DScene d{};
     DevBuf obj, tlas, blas, tri, tri_attr, mat, tex, images, hdr;
-    uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0;
+    uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mat = 0, n_tex = 0;
     bool hdr_env = false;
     // workspace (grown on demand, reused across fw_render calls)
-    DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, accum, counts, pixel_ids, out_rgb8, out_gamma, out_linear;
+    DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, accum, wcount, totals, pixel_ids, out_rgb8, out_gamma, out_linear;
     std::vector<hipEvent_t> events;
     ~fw_scene() {
         for (DevBuf *b : {&obj, &tlas, &blas, &tri, &tri_attr, &mat, &tex, &images, &hdr, &ray_a[0], &ray_a[1], &ray_b[0], &ray_b[1],
-                          &state[0], &state[1], &hits, &sample_rad, &accum, &counts, &pixel_ids, &out_rgb8, &out_gamma, &out_linear})
+                          &state[0], &state[1], &hits, &sample_rad, &accum, &wcount, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
     }
@@ -337,8 +337,21 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         if (m.kind < FW_MAT_LAMBERTIAN || m.kind > FW_MAT_ISOTROPIC) return fail(FW_ERR_BAD_ARG, "unknown material kind");
         bool needs_tex = m.kind == FW_MAT_LAMBERTIAN || m.kind == FW_MAT_EMISSIVE || m.kind == FW_MAT_ISOTROPIC;
         if (needs_tex && (m.texture < 0 || (uint32_t)m.texture >= desc->n_textures)) return fail(FW_ERR_BAD_ARG, "material texture out of range");
-        q[0] = bits_f((uint32_t)m.kind); q[1] = bits_f((uint32_t)(needs_tex ? m.texture : 0)); q[2] = m.roughness; q[3] = m.ref_idx;
+        uint32_t mbits = (uint32_t)m.kind;
         q[4] = m.albedo.x; q[5] = m.albedo.y; q[6] = m.albedo.z;
+        if (needs_tex) {
+            const fw_texture &t = desc->textures[m.texture];
+            if (t.kind == FW_TEX_CONSTANT) { mbits |= fw::MF_TEX_CONST; q[4] = t.color.x; q[5] = t.color.y; q[6] = t.color.z; }
+            // uv are consumed by ImageTexture only: walk the (checker) tree
+            std::vector<int32_t> todo{m.texture};
+            for (int guard = 0; !todo.empty() && guard < 4096; guard++) {
+                const fw_texture &c = desc->textures[todo.back()];
+                todo.pop_back();
+                if (c.kind == FW_TEX_IMAGE) mbits |= fw::MF_NEEDS_UV;
+                if (c.kind == FW_TEX_CHECKER) { todo.push_back(c.odd); todo.push_back(c.even); }
+            }
+        }
+        q[0] = bits_f(mbits); q[1] = bits_f((uint32_t)(needs_tex ? m.texture : 0)); q[2] = m.roughness; q[3] = m.ref_idx;
     }
     const fw_environment &e = desc->environment;
     if (e.kind < FW_ENV_COLOR || e.kind > FW_ENV_HDR) return fail(FW_ERR_BAD_ARG, "unknown environment kind");
@@ -376,6 +389,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     sc->hdr_env = e.kind == FW_ENV_HDR;
     sc->tlas_nodes = tlas.count(); sc->blas_nodes = fl.blas.count();
     sc->tlas_depth = tlas.depth; sc->blas_depth = fl.blas_depth;
+    sc->n_mat = desc->n_materials; sc->n_tex = desc->n_textures;
     *out = sc;
     return FW_OK;
 }
@@ -400,9 +414,15 @@ fw::DCamera make_camera(const fw_camera_settings &s, uint32_t width, uint32_t he
     return c;
 }
 
+// Wavefront pool size.  Bigger is better on this part: fewer, fuller launches and longer wave-private queues
+// (measured on cornell 512x512@1024: 4 Mi paths 85 ms/frame, 16 Mi 64 ms, 256 Mi = the whole frame 55 ms).
+// Default: up to 2^28 path slots (112 B each = 30 GB), never more than half of the free HBM.
 uint32_t default_paths_per_batch() {
-    if (const char *e = getenv("FIREWORK_PATHS_PER_BATCH")) { long v = atol(e); if (v > 0) return (uint32_t)v; }
-    return 1u << 22;
+    if (const char *e = getenv("FIREWORK_PATHS_PER_BATCH")) { long long v = atoll(e); if (v > 0) return (uint32_t)std::min<long long>(v, 0x7fffffffll); }
+    size_t free_b = 0, total_b = 0;
+    uint64_t budget = 1ull << 28;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, (uint64_t)(free_b / 2) / 112u);
+    return (uint32_t)std::max<uint64_t>(budget, 1u << 16);
 }
 
 int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats) {
@@ -421,18 +441,33 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch();
     uint32_t spp_b = std::max<uint32_t>(1u, budget / n_pix);
     spp_b = std::min(spp_b, p->samples);
-    uint64_t cap64 = (uint64_t)n_pix * spp_b;
-    if (cap64 > 0x7fffffffull) return fail(FW_ERR_UNSUPPORTED, "too many paths per batch");
-    uint32_t cap = (uint32_t)cap64;
+    uint64_t paths64 = (uint64_t)n_pix * spp_b;
+    if (paths64 > 0x7fffffffull) return fail(FW_ERR_UNSUPPORTED, "too many paths per batch");
+    uint32_t max_paths = (uint32_t)paths64;
     uint32_t n_batches = (p->samples + spp_b - 1) / spp_b;
+
+    // wave-private queues: ~8 resident-size rounds of waves, each owning >= 8 chunks of 64 paths when the batch allows
+    fw::DQueue q;
+    uint32_t want_waves = (uint32_t)sc->n_cus * 512u;
+    if (const char *e = getenv("FIREWORK_WAVES")) { long v = atol(e); if (v > 0) want_waves = (uint32_t)v; }
+    q.n_waves = std::max(4u, std::min(want_waves, (max_paths + 511u) / 512u));
+    q.n_waves = (q.n_waves + 3u) & ~3u;
+    uint32_t chunks_per_wave = (max_paths + q.n_waves * 64u - 1) / (q.n_waves * 64u);
+    q.cpw_shift = 0;
+    while ((1u << q.cpw_shift) < chunks_per_wave) q.cpw_shift++;      // power of two: chunk -> (wave, row) is a shift
+    q.cap = 64u << q.cpw_shift;
+    uint64_t cap64 = (uint64_t)q.cap * q.n_waves;
+    if (cap64 > 0x7fffffffull) return fail(FW_ERR_UNSUPPORTED, "too many path slots");
+    uint32_t cap = (uint32_t)cap64;
 
     int rc = FW_OK;
     auto need = [&](DevBuf &b, size_t n) { if (!rc) rc = b.alloc(n); };
     for (int k = 0; k < 2; k++) { need(sc->ray_a[k], (size_t)cap * 16); need(sc->ray_b[k], (size_t)cap * 8); need(sc->state[k], (size_t)cap * 16); }
     need(sc->hits, (size_t)cap * 16);
-    need(sc->sample_rad, (size_t)cap * 16);
+    need(sc->sample_rad, (size_t)max_paths * 16);
     need(sc->accum, (size_t)n_pix * 16);
-    need(sc->counts, (size_t)n_batches * fw::COUNT_STRIDE * 4);
+    need(sc->wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
+    need(sc->totals, (size_t)n_batches * fw::COUNT_STRIDE * 4);
     if (p->pixel_ids) need(sc->pixel_ids, (size_t)n_pix * 4);
     uint8_t *d_rgb8 = rgb8; float *d_gamma = gamma_rgb, *d_linear = linear_rgb;
     if (!p->outputs_on_device) {
@@ -441,34 +476,37 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         if (linear_rgb) { need(sc->out_linear, (size_t)n_pix * 12); d_linear = (float *)sc->out_linear.p; }
     }
     if (rc) return rc;
+    q.wcount = (uint32_t *)sc->wcount.p;
     if (p->pixel_ids) HIPCHK(hipMemcpyAsync(sc->pixel_ids.p, p->pixel_ids, (size_t)n_pix * 4, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(sc->accum.p, 0, (size_t)n_pix * 16, stream));
-    HIPCHK(hipMemsetAsync(sc->counts.p, 0, (size_t)n_batches * fw::COUNT_STRIDE * 4, stream));
+    HIPCHK(hipMemsetAsync(sc->totals.p, 0, (size_t)n_batches * fw::COUNT_STRIDE * 4, stream));
 
     fw::LaunchCfg cfg;
     cfg.stream = stream;
+    cfg.q = q;
     int max_blocks = sc->n_cus * 8;
-    auto blocks_for = [&](uint64_t n) { return (int)std::max<uint64_t>(1, std::min<uint64_t>((n + fw::BLOCK - 1) / fw::BLOCK, (uint64_t)max_blocks)); };
-    cfg.blocks_extend = blocks_for(cap); cfg.blocks_shade = blocks_for(cap); cfg.blocks_other = blocks_for(cap);
+    cfg.blocks_other = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_pix + fw::BLOCK - 1) / fw::BLOCK, (uint64_t)max_blocks));
     cfg.tlas_depth = (int)sc->tlas_depth; cfg.blas_depth = (int)sc->blas_depth;
+    cfg.n_mat = sc->n_mat; cfg.n_tex = sc->n_tex;
+    cfg.lds_tables = getenv("FIREWORK_NO_LDS_TABLES") == nullptr;
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
-    fr.width = p->width; fr.height = p->height; fr.n_pixels = n_pix;
+    fr.width = p->width; fr.height = p->height; fr.n_pixels = n_pix; fr.inv_n_pixels = 1.0f / (float)n_pix; fr.inv_width = 1.0f / (float)p->width;
     fr.pixel_ids = p->pixel_ids ? (const uint32_t *)sc->pixel_ids.p : nullptr;
     fr.seed32 = (uint32_t)p->seed ^ ((uint32_t)(p->seed >> 32) * 0x9E3779B9u);
 
-    // events: [0]=start [1]=stop, then per-launch pairs when FW_FLAG_TIME_KERNELS
+    // events: [0]=start [1]=stop; with FW_FLAG_TIME_KERNELS one extra event after every launch (the end of
+    // launch k is the start of launch k+1, so N launches cost N events, not 2N)
     const bool timing = (p->flags & FW_FLAG_TIME_KERNELS) != 0;
-    size_t per_batch_launches = 1 + 2 * fw::MAX_SEGMENTS + 1;
-    size_t n_events = 2 + (timing ? 2 * (per_batch_launches * n_batches + 1) : 0);
+    size_t per_batch_launches = 1 + 2 * fw::MAX_SEGMENTS + 2;
+    size_t n_events = 2 + (timing ? (per_batch_launches * n_batches + 2) : 0);
     while (sc->events.size() < n_events) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); sc->events.push_back(e); }
     size_t ev = 2;
-    std::vector<int> ev_class;   // 0 raygen 1 extend 2 shade 3 accumulate/resolve
+    std::vector<int> ev_class;   // 0 raygen 1 extend 2 shade 3 accumulate/resolve/totals
     auto timed = [&](int cls, auto &&launch) {
-        if (timing) (void)hipEventRecord(sc->events[ev], stream);
         launch();
-        if (timing) { (void)hipEventRecord(sc->events[ev + 1], stream); ev += 2; ev_class.push_back(cls); }
+        if (timing) { (void)hipEventRecord(sc->events[ev], stream); ev++; ev_class.push_back(cls); }
     };
 
     fw::DPaths buf[2];
@@ -481,14 +519,15 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         fr.sample0 = b * spp_b;
         fr.spp_batch = std::min(spp_b, p->samples - fr.sample0);
         uint32_t n_paths = n_pix * fr.spp_batch;
-        uint32_t *counts = (uint32_t *)sc->counts.p + (size_t)b * fw::COUNT_STRIDE;
+        uint32_t *totals = (uint32_t *)sc->totals.p + (size_t)b * fw::COUNT_STRIDE;
         int cur = 0;
-        timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], counts, n_paths); });
+        timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], n_paths); });
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
-            timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, counts, seg, use_bvh); });
-            timed(2, [&] { fw::launch_shade(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], hits, srad, counts, seg); });
+            timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh); });
+            timed(2, [&] { fw::launch_shade(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], hits, srad, seg); });
             cur ^= 1;
         }
+        timed(3, [&] { fw::launch_queue_totals(cfg, totals); });
         timed(3, [&] { fw::launch_accumulate(cfg, fr, srad, accum); });
     }
     timed(3, [&] { fw::launch_resolve(cfg, fr, accum, p->samples, p->gamma, d_rgb8, d_gamma, d_linear); });
@@ -496,7 +535,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     HIPCHK(hipGetLastError());
 
     std::vector<uint32_t> h_counts((size_t)n_batches * fw::COUNT_STRIDE);
-    HIPCHK(hipMemcpyAsync(h_counts.data(), sc->counts.p, h_counts.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_counts.data(), sc->totals.p, h_counts.size() * 4, hipMemcpyDeviceToHost, stream));
     if (!p->outputs_on_device) {
         if (rgb8) HIPCHK(hipMemcpyAsync(rgb8, d_rgb8, (size_t)n_pix * 3, hipMemcpyDeviceToHost, stream));
         if (gamma_rgb) HIPCHK(hipMemcpyAsync(gamma_rgb, d_gamma, (size_t)n_pix * 12, hipMemcpyDeviceToHost, stream));
@@ -517,7 +556,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             double acc[4] = {0, 0, 0, 0};
             for (size_t i = 0; i < ev_class.size(); i++) {
                 float t = 0.f;
-                HIPCHK(hipEventElapsedTime(&t, sc->events[2 + 2 * i], sc->events[3 + 2 * i]));
+                HIPCHK(hipEventElapsedTime(&t, i == 0 ? sc->events[0] : sc->events[1 + i], sc->events[2 + i]));
                 acc[ev_class[i]] += t;
             }
             stats->ms_raygen = acc[0]; stats->ms_extend = acc[1]; stats->ms_shade = acc[2]; stats->ms_accumulate = acc[3];
@@ -558,6 +597,22 @@ int fw_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+int fw_selftest_arith(int device, uint32_t n, uint32_t seed, int mode, uint64_t *div_mismatches, uint64_t *sqrt_mismatches) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FW_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev || !div_mismatches || !sqrt_mismatches) return fail(FW_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(device));
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    HIPCHK(hipMalloc(&d, sizeof h));
+    HIPCHK(hipMemset(d, 0, sizeof h));
+    fw::launch_selftest_arith(nullptr, n, seed, mode, d);
+    hipError_t e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(FW_ERR_HIP, hipGetErrorString(e));
+    *div_mismatches = h[0]; *sqrt_mismatches = h[1];
+    return FW_OK;
 }
 
 int fw_scene_create(const fw_scene_desc *desc, int device, fw_scene **out) {

@@ -23,14 +23,15 @@ def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
     tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
     os.makedirs("profiles", exist_ok=True)
-    ks = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+    newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]   # gpurun merges runs additively
+    ks = newest(f"{src}/trace/*/*_kernel_stats.csv")
     if ks:
         shutil.copyfile(ks[0], f"profiles/{tag}_kernel_stats.csv")
     out = {"command": "rocprofv3 --pmc <C> --kernel-trace --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline",
            "note": "bytes = Counter_Value * 1024; read side doubled (gfx950 FETCH_SIZE = 1/2 of wide coalesced reads)",
            "kernels": {}}
     for cname, key, mul in (("fetch", "read_bytes", 2.0 * 1024), ("write", "write_bytes", 1024.0)):
-        fs = glob.glob(f"{src}/{cname}/*/*_counter_collection.csv")
+        fs = newest(f"{src}/{cname}/*/*_counter_collection.csv")
         if not fs:
             continue
         tot, cnt = collections.defaultdict(float), collections.Counter()

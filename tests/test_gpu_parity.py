@@ -46,6 +46,16 @@ def test_device_present():
     assert _lib.device_count() >= 1
 
 
+def test_division_and_sqrt_helpers_are_ieee_exact():
+    """fw_kernels.hip's fdiv/fsqrt (Newton/residual chain without v_div_scale) vs the compiler's `/` and sqrtf,
+    bit for bit: exact on renderer-range operands; the full-range count is reported (scaling cases only)."""
+    d, s = _lib.selftest_arith(1 << 26, seed=7, mode=0)
+    assert (d, s) == (0, 0)
+    d1, s1 = _lib.selftest_arith(1 << 24, seed=9, mode=1)
+    print(f"full-range mismatches out of {1 << 24}: div={d1} sqrt={s1}")
+    assert d1 < (1 << 24) * 0.2 and s1 < (1 << 24) * 0.2
+
+
 def test_cornell_box(oracle):                      # C2: rects + rotated boxes + emissive, linear scene
     s, r = scenes.config("C2_cornell_box", 64, 64, 64)
     gpu, cpu = check(oracle, s, r)
