@@ -1,0 +1,74 @@
+"""The reference's YAML wire format (serde_yaml + typetag): round trips, and the reference's own scene files
+when /root/reference is present (build container only; skipped on the GPU box)."""
+import os
+
+import numpy as np
+import pytest
+import yaml
+
+from firework_amd import scenes
+from firework_amd.api import Renderer
+from firework_amd.yaml_io import UnsupportedShape, load_scene, save_scene, scene_to_dict
+
+REF = "/root/reference"
+
+
+def _same_render(oracle, a, b):
+    r = Renderer.default().width(24).height(16).samples(2).use_bvh(True)
+    ra, rb = oracle.render(a, r), oracle.render(b, r)
+    assert np.array_equal(ra.linear, rb.linear)
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "suzanne", "volume_test", "random_spheres"])
+def test_round_trip(oracle, tmp_path, name):
+    scene, _ = getattr(scenes, name)()
+    p = tmp_path / f"{name}.yml"
+    save_scene(scene, p)
+    back = load_scene(p)
+    assert scene_to_dict(back) == scene_to_dict(scene)
+    _same_render(oracle, scene, back)
+
+
+def test_schema_spelling():
+    d = scene_to_dict(scenes.volume_test()[0])
+    ro = d["render_objects"][0]
+    assert set(ro) == {"obj", "position", "rotation", "flip_normals"}
+    assert ro["obj"]["object_type"] == "ConstantMedium" and ro["obj"]["obj"]["object_type"] == "Sphere"
+    assert set(ro["rotation"]) == {"s", "bv"} and set(ro["rotation"]["bv"]) == {"xy", "xz", "yz"}
+    assert d["materials"][0] == {"material": "DielectricMat", "ref_idx": 1.5}
+    assert d["environment"]["environment"] == "SkyEnv"
+    box = scene_to_dict(scenes.cornell_box()[0])["render_objects"][6]["obj"]
+    assert [list(f)[0] for f in box["faces"]] == ["XY", "XY", "XZ", "XZ", "YZ", "YZ"]      # rect3d.rs:19-77
+
+
+@pytest.mark.skipif(not os.path.exists(f"{REF}/scenes/suzanne.yml"), reason="reference tree not present")
+def test_reads_reference_suzanne_yml_and_matches_our_builder():
+    ref = load_scene(f"{REF}/scenes/suzanne.yml")
+    ours, _ = scenes.suzanne()
+    dr, do = scene_to_dict(ref), scene_to_dict(ours)
+    assert dr["materials"] == do["materials"] and dr["environment"] == do["environment"]
+    for a, b in zip(dr["render_objects"], do["render_objects"]):
+        assert a == b
+    # and our writer reproduces the reference file's data exactly
+    with open(f"{REF}/scenes/suzanne.yml") as f:
+        raw = yaml.load(f, Loader=getattr(yaml, "CSafeLoader", yaml.SafeLoader))
+    assert raw == do
+
+
+@pytest.mark.skipif(not os.path.exists(f"{REF}/scenes/teapot.yml"), reason="reference tree not present")
+def test_reads_reference_teapot_yml_with_vertex_normals(oracle):
+    sc = load_scene(f"{REF}/scenes/teapot.yml")
+    meshes = [ro.obj for ro in sc.render_objects if type(ro.obj).__name__ == "TriangleMesh"]
+    assert len(meshes) == 4 and sum(m.num_tris() for m in meshes) == 6320
+    assert all(m.normals is not None for m in meshes)
+    r = Renderer.default().width(32).height(18).samples(2).use_bvh(True)
+    from firework_amd.api import CameraSettings
+    r.camera(CameraSettings.default().cam_pos((0.0, 30.0, 50.0)).look_at((0.0, 0.0, 0.0)).field_of_view(40.0))
+    img = oracle.render(sc, r)
+    assert np.isfinite(img.linear).all() and img.linear.max() > 0
+
+
+@pytest.mark.skipif(not os.path.exists(f"{REF}/scenes/conics.yml"), reason="reference tree not present")
+def test_conics_are_reported_not_misrendered():
+    with pytest.raises(UnsupportedShape):
+        load_scene(f"{REF}/scenes/conics.yml")
