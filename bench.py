@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (=RCCL over xGMI) for real multi-GPU runs; gloo stages the gather through host memory and "
+                         "lets several ranks share one GPU — a functional rehearsal of the N>1 path on a 1-GPU box")
     args = ap.parse_args()
 
     import numpy as np
@@ -51,10 +54,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    n_dev = torch.cuda.device_count()
+    device_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group("gloo")
 
     scene, renderer = scenes.config(args.config, args.width, args.height, args.spp)
     if args.paths_per_batch:
@@ -62,7 +70,8 @@ def main():
     if not args.no_kernel_timing:
         renderer.time_kernels(True)
     s = renderer.settings
-    tr = TiledRenderer(scene, renderer, rank, world, local_rank, dist=dist if world > 1 else None)
+    tr = TiledRenderer(scene, renderer, rank, world, device_index, dist=dist if world > 1 else None,
+                       host_staged_gather=(args.backend == "gloo"))
 
     def barrier():
         if world > 1:
@@ -84,7 +93,7 @@ def main():
 
     # max over ranks of the elapsed time; sums over ranks of the work counters
     vec = torch.tensor([elapsed, acc["rays"], acc["samples"], acc["ms_extend"], acc["ms_shade"], acc["ms_render"]],
-                       dtype=torch.float64, device="cuda")
+                       dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         mx = vec.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -108,7 +117,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config} {s['width']}x{s['height']} @{s['samples']}spp", "use_bvh": bool(s["use_bvh"]),
-                       "tiles": "32x32 round-robin over ranks", "collective": "one gather of u8 tiles to rank 0" if world > 1 else "none",
+                       "tiles": "32x32 round-robin over ranks", "collective": f"one gather of u8 tiles to rank 0 ({args.backend})" if world > 1 else "none",
                        "rng": "counter (pcg4d) keyed by (seed,pixel,sample,dimension)", "seed": s["seed"]},
             "msamples_per_s": total_samples / elapsed / 1e6,
             "frame_time_ms": ms_step,

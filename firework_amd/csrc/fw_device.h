@@ -33,7 +33,7 @@ enum : uint32_t {
 
 // ---- BVH node: 2 x float4 = 32 B.  DFS order: the left child of node i is i+1.
 //   lo = (min.xyz, bits A)   hi = (max.xyz, bits B)
-//   A>>30 == 0: Branch      right child = A & 0x3fffffff
+//   A>>30 == 0: Branch      right child = A & 0x3fffffff, B = split axis (depth % 3)
 //   A>>30 == 1: Leaf        item = A & 0x3fffffff
 //   A>>30 == 2: DoubleLeaf  items = A & 0x3fffffff, B
 constexpr uint32_t MF_NEEDS_UV = 1u << 8;    // the material's texture tree contains an ImageTexture
@@ -63,7 +63,9 @@ struct DScene {
     const float4 *tlas;
     const float4 *blas;
     const float4 *tri;
-    const float4 *tri_nrm;   // same indexing as tri; valid only for meshes with OF_MESH_NORMALS
+    const float4 *tri_nrm;   // same indexing as tri; valid only for meshes with OF_MESH_ATTR
+    const uint32_t *tri_rank; // in-order rank of each triangle in the REFERENCE tree of its mesh (tie-breaking)
+    const uint32_t *obj_rank; // same for objects in the reference TLAS
     const float4 *mat;
     const float4 *tex;
     const uint8_t *images;

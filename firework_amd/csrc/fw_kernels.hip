@@ -346,11 +346,13 @@ struct LdsStack {
     __device__ __forceinline__ uint32_t pop() { sp--; return s[sp * FW_WB]; }
 };
 
-// K4  mesh BLAS (bvh.rs:100-151 over Triangle items).  The reference visits both children with the
-// caller's [tmin,tmax] and keeps the smaller t, the right/later item winning ties.  Here: in-order DFS,
-// boxes are culled against the best t so far (which cannot remove the eventual winner except when it
-// lies exactly on a box's entry plane), every triangle is still tested against the caller's tmax, and
-// a later triangle replaces the current one unless current.t < t — the same winner.
+// K4  mesh BLAS (bvh.rs:100-151 over Triangle items).  The reference visits BOTH children with the caller's
+// [tmin,tmax] and keeps the smaller t, the right/later item winning ties.  Here: front-to-back traversal
+// (a Branch's children are split along axis depth%3, so the sign of the ray direction on that axis picks the
+// near child), boxes culled against the best t so far, every triangle still tested against the caller's tmax,
+// and ties resolved by the item's in-order rank in the REFERENCE tree (tri_rank / obj_rank, fetched only on a
+// tie) — the reference's winner in any visiting order and for any tree topology (the walked tree is SAH-built).  Differs only if the winning hit lies exactly on a culled
+// box's entry plane, or for NaN t.
 __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32_t tri_base, const Ray &r, float tmin,
                                          float tmax, uint32_t *stack_base, float &t_out, uint32_t &tri_out) {
     V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
@@ -362,7 +364,13 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
         if (hit_aabb(lo, hi, r.o, inv, tmin, have ? best : tmax)) {
             uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
             uint32_t kind = A >> 30;
-            if (kind == 0) { st.push(A & NODE_MASK); node = node + 1; continue; }
+            if (kind == 0) {
+                bool left_first = comp(r.d, (int)(B & 3u)) >= 0.f;
+                uint32_t left = node + 1, right = A & NODE_MASK;
+                st.push(left_first ? right : left);
+                node = left_first ? left : right;
+                continue;
+            }
             uint32_t items[2] = {A & NODE_MASK, B};
             int n_items = (kind == NODE_DOUBLE) ? 2 : 1;
             for (int q = 0; q < n_items; q++) {
@@ -370,7 +378,8 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, b0, b1, b2;
                 if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), r, tmin, tmax, t, b0, b1, b2)) {
-                    if (!have || !(best < t)) { have = true; best = t; best_tri = items[q]; }
+                    // tie -> the item that comes later in the reference tree's in-order (ranks fetched only then)
+                    if (!have || t < best || (t == best && sc.tri_rank[tri_base + items[q]] > sc.tri_rank[tri_base + best_tri])) { have = true; best = t; best_tri = items[q]; }
                 }
             }
         }
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
                 if (hit_object(sc, o, j, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = j; best_prim = prim; }
             }
         } else {
-            // bvh.rs:88-98,115-151 over RenderObjectInternal items; same in-order scheme as hit_mesh
+            // bvh.rs:88-98,115-151 over RenderObjectInternal items; same front-to-back scheme as hit_mesh
             V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
             LdsStack st{my_stack, 0};
             bool have = false;
@@ -468,14 +477,20 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
                 if (hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX)) {
                     uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
                     uint32_t kind = A >> 30;
-                    if (kind == 0) { st.push(A & NODE_MASK); node = node + 1; continue; }
+                    if (kind == 0) {
+                        bool left_first = comp(r.d, (int)(B & 3u)) >= 0.f;
+                        uint32_t left = node + 1, right = A & NODE_MASK;
+                        st.push(left_first ? right : left);
+                        node = left_first ? left : right;
+                        continue;
+                    }
                     uint32_t items[2] = {A & NODE_MASK, B};
                     int n_items = (kind == NODE_DOUBLE) ? 2 : 1;
                     for (int q = 0; q < n_items; q++) {
                         Obj o = load_obj(sc.obj, items[q]);
                         float t; uint32_t prim;
                         if (hit_object(sc, o, items[q], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
-                            if (!have || !(best_t < t)) { have = true; best_t = t; best_obj = items[q]; best_prim = prim; }
+                            if (!have || t < best_t || (t == best_t && sc.obj_rank[items[q]] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = items[q]; best_prim = prim; }
                         }
                     }
                 }

@@ -97,6 +97,7 @@ uint32_t bvh_build_rec(FlatBvh &out, const std::vector<Box> &boxes, uint32_t *id
         uint32_t right = bvh_build_rec(out, boxes, idx + half, n - half, depth + 1, rb);
         node_box = box_union(lb, rb);
         A = right;
+        B = (uint32_t)axis;     // split axis of this Branch (depth % 3): picks the near child during traversal
     }
     float *p = &out.nodes[(size_t)me * 8];
     p[0] = node_box.mn.x; p[1] = node_box.mn.y; p[2] = node_box.mn.z; p[3] = bits_f(A);
@@ -110,6 +111,94 @@ Box bvh_build(FlatBvh &out, const std::vector<Box> &boxes) {
     bvh_build_rec(out, boxes, idx.data(), idx.size(), 0, root);
     return root;
 }
+
+// In-order rank of every item in the reference (median-split) tree: leaves appear left to right in DFS order.
+std::vector<uint32_t> reference_ranks(const FlatBvh &ref, size_t n_items) {
+    std::vector<uint32_t> rank(n_items, 0);
+    uint32_t next = 0;
+    for (uint32_t i = 0; i < ref.count(); i++) {
+        uint32_t A, B; std::memcpy(&A, &ref.nodes[(size_t)i * 8 + 3], 4); std::memcpy(&B, &ref.nodes[(size_t)i * 8 + 7], 4);
+        uint32_t kind = A >> 30;
+        if (kind == fw::NODE_LEAF) rank[A & fw::NODE_MASK] = next++;
+        else if (kind == fw::NODE_DOUBLE) { rank[A & fw::NODE_MASK] = next++; rank[B] = next++; }
+    }
+    return rank;
+}
+
+// ---- traversal tree: binned-SAH top-down build, same node format (leaves of 1 or 2 items, DFS order).
+// The reference's tree (bvh_build above) fixes WHICH hit wins ties (in-order rank); it does not have to be the
+// tree that is walked.  SAH isolates large items near the root (part2's r=5000 fog sphere otherwise inflates
+// every ancestor box along its spine) and splits on the axis that actually separates the items.
+constexpr uint32_t SAH_MAX_DEPTH = 40;
+inline float box_area(const Box &b) { V3 d = b.mx - b.mn; return 2.f * (d.x * d.y + d.y * d.z + d.z * d.x); }
+
+uint32_t sah_build_rec(FlatBvh &out, const std::vector<Box> &boxes, uint32_t *idx, size_t n, uint32_t depth, Box &node_box) {
+    uint32_t me = out.count();
+    out.nodes.resize(out.nodes.size() + 8);
+    out.depth = std::max(out.depth, depth);
+    uint32_t A, B = 0;
+    if (n == 1) { node_box = boxes[idx[0]]; A = (fw::NODE_LEAF << 30) | idx[0]; }
+    else if (n == 2) { node_box = box_union(boxes[idx[0]], boxes[idx[1]]); A = (fw::NODE_DOUBLE << 30) | idx[0]; B = idx[1]; }
+    else {
+        Box cb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
+        for (size_t i = 0; i < n; i++) { V3 c = box_center(boxes[idx[i]]); cb.mn = vmin(cb.mn, c); cb.mx = vmax(cb.mx, c); }
+        int best_axis = -1; size_t best_split = 0; float best_cost = 1e38f;
+        constexpr int NB = 16;
+        if (depth < SAH_MAX_DEPTH) for (int axis = 0; axis < 3; axis++) {
+            float lo = cb.mn[axis], ext = cb.mx[axis] - lo;
+            if (!(ext > 0.f)) continue;
+            Box bb[NB]; size_t bc[NB];
+            for (int k = 0; k < NB; k++) { bb[k] = {{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}}; bc[k] = 0; }
+            for (size_t i = 0; i < n; i++) {
+                int k = std::min(NB - 1, std::max(0, (int)((box_center(boxes[idx[i]])[axis] - lo) / ext * NB)));
+                bb[k] = box_union(bb[k], boxes[idx[i]]); bc[k]++;
+            }
+            float la[NB], ra[NB]; size_t lc[NB], rc[NB];
+            Box acc{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}}; size_t cnt = 0;
+            for (int k = 0; k < NB; k++) { if (bc[k]) acc = box_union(acc, bb[k]); cnt += bc[k]; la[k] = cnt ? box_area(acc) : 0.f; lc[k] = cnt; }
+            acc = {{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}}; cnt = 0;
+            for (int k = NB - 1; k >= 0; k--) { if (bc[k]) acc = box_union(acc, bb[k]); cnt += bc[k]; ra[k] = cnt ? box_area(acc) : 0.f; rc[k] = cnt; }
+            for (int k = 0; k + 1 < NB; k++) {
+                if (lc[k] == 0 || rc[k + 1] == 0) continue;
+                float cost = la[k] * (float)lc[k] + ra[k + 1] * (float)rc[k + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = (size_t)k; }
+            }
+        }
+        size_t half;
+        int axis;
+        if (best_axis >= 0) {
+            axis = best_axis;
+            float lo = cb.mn[axis], ext = cb.mx[axis] - lo;
+            auto mid = std::stable_partition(idx, idx + n, [&](uint32_t a) {
+                int k = std::min(NB - 1, std::max(0, (int)((box_center(boxes[a])[axis] - lo) / ext * NB)));
+                return (size_t)k <= best_split; });
+            half = (size_t)(mid - idx);
+        } else {   // all centroids coincide (or depth cap): median split keeps the tree balanced
+            V3 e = cb.mx - cb.mn;
+            axis = e.x >= e.y ? (e.x >= e.z ? 0 : 2) : (e.y >= e.z ? 1 : 2);
+            std::stable_sort(idx, idx + n, [&](uint32_t a, uint32_t b) { return box_center(boxes[a])[axis] < box_center(boxes[b])[axis]; });
+            half = n / 2;
+        }
+        if (half == 0 || half == n) half = n / 2;
+        Box lb, rb;
+        sah_build_rec(out, boxes, idx, half, depth + 1, lb);
+        uint32_t right = sah_build_rec(out, boxes, idx + half, n - half, depth + 1, rb);
+        node_box = box_union(lb, rb);
+        A = right;
+        B = (uint32_t)axis;     // left child holds the smaller centroids along this axis
+    }
+    float *p = &out.nodes[(size_t)me * 8];
+    p[0] = node_box.mn.x; p[1] = node_box.mn.y; p[2] = node_box.mn.z; p[3] = bits_f(A);
+    p[4] = node_box.mx.x; p[5] = node_box.mx.y; p[6] = node_box.mx.z; p[7] = bits_f(B);
+    return me;
+}
+void sah_build(FlatBvh &out, const std::vector<Box> &boxes) {
+    std::vector<uint32_t> idx(boxes.size());
+    for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)i;
+    Box root;
+    sah_build_rec(out, boxes, idx.data(), idx.size(), 0, root);
+}
+inline bool use_sah() { const char *e = getenv("FIREWORK_BVH"); return !(e && std::strcmp(e, "median") == 0); }
 
 // ---- device allocations owned by a scene / workspace ----------------------------------------------------
 struct DevBuf {
@@ -137,14 +226,14 @@ struct fw_scene {
     int device = 0;
     int n_cus = 256;
     fw::DScene d{};
-    DevBuf obj, tlas, blas, tri, tri_attr, mat, tex, images, hdr;
+    DevBuf obj, tlas, blas, tri, tri_attr, tri_rank, obj_rank, mat, tex, images, hdr;
     uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mat = 0, n_tex = 0;
     bool hdr_env = false;
     // workspace (grown on demand, reused across fw_render calls)
     DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, accum, wcount, totals, pixel_ids, out_rgb8, out_gamma, out_linear;
     std::vector<hipEvent_t> events;
     ~fw_scene() {
-        for (DevBuf *b : {&obj, &tlas, &blas, &tri, &tri_attr, &mat, &tex, &images, &hdr, &ray_a[0], &ray_a[1], &ray_b[0], &ray_b[1],
+        for (DevBuf *b : {&obj, &tlas, &blas, &tri, &tri_attr, &tri_rank, &obj_rank, &mat, &tex, &images, &hdr, &ray_a[0], &ray_a[1], &ray_b[0], &ray_b[1],
                           &state[0], &state[1], &hits, &sample_rad, &accum, &wcount, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -158,9 +247,10 @@ struct ShapeParams { float q3[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0}; uint32_t 
 struct Flattener {
     const fw_scene_desc *d;
     std::vector<float> tri, tri_attr;     // 12 floats per triangle each
+    std::vector<uint32_t> tri_rank;       // in-order rank of each triangle in the reference tree of its mesh
     bool any_attr = false;
     FlatBvh blas;
-    uint32_t blas_depth = 0;
+    uint32_t blas_depth = 0, ref_blas_nodes = 0;
 
     int check_material(int32_t m) const { return (m < 0 || (uint32_t)m >= d->n_materials) ? FW_ERR_BAD_ARG : FW_OK; }
 
@@ -239,6 +329,12 @@ struct Flattener {
         }
         FlatBvh local;
         try { sp.box = bvh_build(local, boxes); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
+        {   // ties are resolved by the reference tree's in-order rank, whatever tree is traversed
+            std::vector<uint32_t> rk = reference_ranks(local, n_tris);
+            tri_rank.insert(tri_rank.end(), rk.begin(), rk.end());
+        }
+        ref_blas_nodes += local.count();
+        if (use_sah()) { FlatBvh sah; sah_build(sah, boxes); local = std::move(sah); }
         uint32_t root = blas.count();
         // rebase child links of the local tree into the shared BLAS array
         for (uint32_t i = 0; i < local.count(); i++) {
@@ -308,6 +404,9 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     }
     FlatBvh tlas;
     try { bvh_build(tlas, world); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
+    std::vector<uint32_t> obj_rank = reference_ranks(tlas, desc->n_objects);
+    uint32_t ref_tlas_nodes = tlas.count();
+    if (use_sah()) { FlatBvh sah; sah_build(sah, world); tlas = std::move(sah); }
 
     // materials / textures / images
     std::vector<float> mats((size_t)std::max(1u, desc->n_materials) * 8, 0.f), texs((size_t)std::max(1u, desc->n_textures) * 8, 0.f);
@@ -370,6 +469,8 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     up(sc->tlas, tlas.nodes.data(), tlas.nodes.size() * 4);
     up(sc->blas, fl.blas.nodes.data(), fl.blas.nodes.size() * 4);
     up(sc->tri, fl.tri.data(), fl.tri.size() * 4);
+    up(sc->tri_rank, fl.tri_rank.data(), fl.tri_rank.size() * 4);
+    up(sc->obj_rank, obj_rank.data(), obj_rank.size() * 4);
     if (fl.any_attr) up(sc->tri_attr, fl.tri_attr.data(), fl.tri_attr.size() * 4);
     up(sc->mat, mats.data(), mats.size() * 4);
     up(sc->tex, texs.data(), texs.size() * 4);
@@ -379,6 +480,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     fw::DScene &d = sc->d;
     d.obj = (const float4 *)sc->obj.p; d.tlas = (const float4 *)sc->tlas.p; d.blas = (const float4 *)sc->blas.p;
     d.tri = (const float4 *)sc->tri.p; d.tri_nrm = (const float4 *)sc->tri_attr.p;
+    d.tri_rank = (const uint32_t *)sc->tri_rank.p; d.obj_rank = (const uint32_t *)sc->obj_rank.p;
     d.mat = (const float4 *)sc->mat.p; d.tex = (const float4 *)sc->tex.p; d.images = (const uint8_t *)sc->images.p;
     d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u;
     d.env.kind = e.kind;
@@ -387,7 +489,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.env.horizon[0] = e.horizon.x; d.env.horizon[1] = e.horizon.y; d.env.horizon[2] = e.horizon.z;
     d.env.hdr = (const float *)sc->hdr.p; d.env.hdr_w = e.hdr_w; d.env.hdr_h = e.hdr_h;
     sc->hdr_env = e.kind == FW_ENV_HDR;
-    sc->tlas_nodes = tlas.count(); sc->blas_nodes = fl.blas.count();
+    sc->tlas_nodes = ref_tlas_nodes; sc->blas_nodes = fl.ref_blas_nodes;   // reported: the reference topology (bvh.rs)
     sc->tlas_depth = tlas.depth; sc->blas_depth = fl.blas_depth;
     sc->n_mat = desc->n_materials; sc->n_tex = desc->n_textures;
     *out = sc;

@@ -27,9 +27,10 @@ def tile_pixel_ids(width, height, rank, world, tile=TILE):
 class TileGather:
     """Rank bookkeeping + the one collective.  Device-agnostic (cuda tensors with nccl, cpu tensors with gloo)."""
 
-    def __init__(self, width, height, rank, world, device, dist=None, tile=TILE):
+    def __init__(self, width, height, rank, world, device, dist=None, tile=TILE, host_staged=False):
         import torch
         self.torch, self.dist = torch, dist
+        self.host_staged = host_staged and world > 1
         self.width, self.height, self.rank, self.world, self.device = width, height, rank, world, device
         all_ids = [tile_pixel_ids(width, height, r, world, tile) for r in range(world)]
         self.ids = np.ascontiguousarray(all_ids[rank])
@@ -49,7 +50,14 @@ class TileGather:
             self.frame.index_copy_(0, self.all_ids_dev[0], self.local[: self.n_local])
             return self.frame
         # the only collective of the whole path: <= W*H*3 bytes in total
-        self.dist.gather(self.local, self.gather_list if self.rank == 0 else None, dst=0)
+        if self.host_staged:     # rehearsal mode (gloo): same call, tensors staged through host memory
+            got = [self.torch.empty((self.n_max, 3), dtype=self.torch.uint8) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(self.local.cpu(), got, dst=0)
+            if self.rank == 0:
+                for r in range(self.world):
+                    self.gather_list[r].copy_(got[r])
+        else:
+            self.dist.gather(self.local, self.gather_list if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
         for r in range(self.world):
@@ -61,14 +69,14 @@ class TiledRenderer:
     """One process per GPU: uploaded scene + this rank's tiles; `render_frame()` = local fw_render into HBM
     + TileGather.assemble()."""
 
-    def __init__(self, scene, renderer, rank=0, world=1, device=0, tile=TILE, dist=None):
+    def __init__(self, scene, renderer, rank=0, world=1, device=0, tile=TILE, dist=None, host_staged_gather=False):
         import torch
         from . import _lib
         self.torch, self.renderer = torch, renderer
         s = renderer.settings
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
-        self.tg = TileGather(s["width"], s["height"], rank, world, self.dev, dist, tile)
+        self.tg = TileGather(s["width"], s["height"], rank, world, self.dev, dist, tile, host_staged=host_staged_gather)
         self.scene = _lib.DeviceScene(scene if hasattr(scene, "ptr") else scene.to_desc(), device)
         self.world = world
         self.last_stats = None
