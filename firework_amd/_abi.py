@@ -1,7 +1,7 @@
 """ctypes mirror of include/firework_hip.h (the C ABI).  Field order and types must match the header."""
 import ctypes as C
 
-FW_ABI_VERSION = 1
+FW_ABI_VERSION = 2
 FW_MAX_SEGMENTS = 11
 
 # fw_status
@@ -21,7 +21,7 @@ FW_ERR_OOM = -10
 FW_TEX_CONSTANT, FW_TEX_CHECKER, FW_TEX_PERLIN, FW_TEX_TURBULENCE, FW_TEX_MARBLE, FW_TEX_IMAGE = range(6)
 FW_MAT_LAMBERTIAN, FW_MAT_METAL, FW_MAT_DIELECTRIC, FW_MAT_EMISSIVE, FW_MAT_ISOTROPIC = range(5)
 (FW_SHAPE_SPHERE, FW_SHAPE_XYRECT, FW_SHAPE_XZRECT, FW_SHAPE_YZRECT, FW_SHAPE_RECT3D,
- FW_SHAPE_TRIANGLE_MESH, FW_SHAPE_CONSTANT_MEDIUM) = range(7)
+ FW_SHAPE_TRIANGLE_MESH, FW_SHAPE_CONSTANT_MEDIUM, FW_SHAPE_CONE, FW_SHAPE_CYLINDER, FW_SHAPE_DISK) = range(10)
 FW_ENV_COLOR, FW_ENV_SKY, FW_ENV_HDR = range(3)
 FW_RNG_CTR, FW_RNG_LCG = 0, 1
 FW_FLAG_TIME_KERNELS = 1
@@ -47,8 +47,8 @@ class fw_material(C.Structure):
 
 
 class fw_shape(C.Structure):
-    _fields_ = [("kind", i32), ("material", i32), ("radius", f32),
-                ("a_min", f32), ("a_max", f32), ("b_min", f32), ("b_max", f32), ("k", f32), ("flip_normal", i32),
+    _fields_ = [("kind", i32), ("material", i32), ("radius", f32), ("height", f32), ("phi_max", f32),
+                ("inner_radius", f32), ("a_min", f32), ("a_max", f32), ("b_min", f32), ("b_max", f32), ("k", f32), ("flip_normal", i32),
                 ("pos", fw_vec3), ("size", fw_vec3),
                 ("verts", C.POINTER(f32)), ("n_verts", u32), ("indices", C.POINTER(u32)), ("n_indices", u32),
                 ("normals", C.POINTER(f32)), ("uvs", C.POINTER(f32)),

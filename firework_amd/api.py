@@ -266,6 +266,55 @@ class Sphere(Shape):
         return Sphere(radius, material)
 
 
+_RADS_PER_DEG = F32(F32(math.pi) / F32(180.0))     # f32::to_radians: self * (PI / 180)
+
+
+@dataclass
+class Cone(Shape):
+    """src/objects/cone.rs:9-25"""
+    radius: float
+    height: float
+    material: int
+
+    @staticmethod
+    def new(radius, height, material):
+        return Cone(radius, height, material)
+
+
+@dataclass
+class Cylinder(Shape):
+    """src/objects/cylinder.rs:10-38 (max_phi in radians)"""
+    radius: float
+    height: float
+    material: int
+    max_phi: float = float(F32(360.0) * _RADS_PER_DEG)
+
+    @staticmethod
+    def new(radius, height, material):
+        return Cylinder(radius, height, material)
+
+    @staticmethod
+    def partial(radius, height, phi, material):
+        return Cylinder(radius, height, material, float(F32(phi) * _RADS_PER_DEG))
+
+
+@dataclass
+class Disk(Shape):
+    """src/objects/disk.rs:10-37 (phi_max in radians)"""
+    radius: float
+    material: int
+    phi_max: float = float(F32(2.0) * F32(math.pi))
+    inner_radius: float = 0.0
+
+    @staticmethod
+    def new(radius, material):
+        return Disk(radius, material)
+
+    @staticmethod
+    def partial(radius, phi, inner_radius, material):
+        return Disk(radius, material, float(F32(phi) * _RADS_PER_DEG), float(inner_radius))
+
+
 @dataclass
 class _AARect(Shape):
     """AARect<A1,A2>::new(a1_min, a1_max, a2_min, a2_max, k, material) (src/objects/rect.rs:24-39)."""
@@ -529,6 +578,12 @@ class SceneDesc:
             fs.inner = -1
             if isinstance(s, Sphere):
                 fs.kind, fs.radius, fs.material = A.FW_SHAPE_SPHERE, s.radius, s.material
+            elif isinstance(s, Cone):
+                fs.kind, fs.material, fs.radius, fs.height = A.FW_SHAPE_CONE, s.material, s.radius, s.height
+            elif isinstance(s, Cylinder):
+                fs.kind, fs.material, fs.radius, fs.height, fs.phi_max = A.FW_SHAPE_CYLINDER, s.material, s.radius, s.height, s.max_phi
+            elif isinstance(s, Disk):
+                fs.kind, fs.material, fs.radius, fs.phi_max, fs.inner_radius = A.FW_SHAPE_DISK, s.material, s.radius, s.phi_max, s.inner_radius
             elif isinstance(s, _AARect):
                 fs.kind, fs.material = s.KIND, s.material
                 fs.a_min, fs.a_max, fs.b_min, fs.b_max, fs.k = s.a_min, s.a_max, s.b_min, s.b_max, s.k

@@ -25,6 +25,7 @@ enum : uint32_t {
 };
 // shape parameters:
 //   sphere : q3.x = radius
+//   cone / cylinder / disk : q3 = (radius height phi_max inner_radius)
 //   rect   : q3 = (a_min a_max b_min b_max)  q4.x = k
 //   rect3d : q3 = (pos.x pos.y pos.z size.x) q4 = (size.y size.z - -)
 //   mesh   : aux0 = BLAS root node index, aux1 = first triangle index

@@ -284,6 +284,74 @@ __device__ __forceinline__ bool hit_rect3d(float4 q3, float4 q4, const Ray &r, f
     return any;
 }
 
+constexpr float PI_F = 3.14159265358979323846f;
+
+// objects/mod.rs:19-31: number of roots (0/1/2) of a t^2 + b t + c
+__device__ __forceinline__ int solve_quadratic(float a, float b, float c, float &t1, float &t2) {
+    float disc = b * b - 4.f * a * c;
+    if (disc < 0.f) return 0;
+    Rcp two_a = make_rcp(2.f * a);
+    if (disc == 0.f) { t1 = fdiv(-b, two_a); t2 = 0.f; return 1; }
+    float sq = fsqrt(disc);
+    t1 = fdiv(-b - sq, two_a); t2 = fdiv(-b + sq, two_a);
+    return 2;
+}
+// objects/cone.rs:26-88 (the accepted root only; normal/uv are rebuilt in k_shade)
+__device__ __forceinline__ bool cone_ok(float height, const Ray &r, float t, float tmin, float tmax) {
+    if (t > tmax || t < tmin) return false;
+    float py = r.o.y + t * r.d.y;
+    return !(py < 0.f || py > height);
+}
+__device__ __forceinline__ bool hit_cone(float radius, float height, const Ray &r, float tmin, float tmax, float &t_out) {
+    V3 o = r.o, d = r.d;
+    float r2_div_h2 = fdiv(radius * radius, height * height);
+    float a = d.x * d.x + d.z * d.z - r2_div_h2 * d.y * d.y;
+    float b = 2.f * (d.x * o.x + d.z * o.z - r2_div_h2 * d.y * (o.y - height));
+    float c = o.x * o.x + o.z * o.z - r2_div_h2 * (o.y - height) * (o.y - height);
+    float t1, t2;
+    int n = solve_quadratic(a, b, c, t1, t2);
+    if (n == 0) return false;
+    if (cone_ok(height, r, t1, tmin, tmax)) { t_out = t1; return true; }
+    if (n == 2 && cone_ok(height, r, t2, tmin, tmax)) { t_out = t2; return true; }
+    return false;
+}
+// objects/cylinder.rs:40-90
+__device__ __forceinline__ bool cylinder_ok(float height, float max_phi, const Ray &r, float t, float tmin, float tmax) {
+    if (t > tmax || t < tmin) return false;
+    V3 p = ray_point(r, t);
+    float phi = atan2f(p.z, p.x);
+    if (phi < 0.f) phi = phi + PI_F * 2.f;
+    return p.y > 0.f && p.y < height && phi < max_phi;
+}
+__device__ __forceinline__ bool hit_cylinder(float radius, float height, float max_phi, const Ray &r, float tmin, float tmax, float &t_out) {
+    V3 o = r.o, d = r.d;
+    float a = d.x * d.x + d.z * d.z;
+    float b = 2.f * (d.x * o.x + d.z * o.z);
+    float c = o.x * o.x + o.z * o.z - radius * radius;
+    float disc = b * b - 4.f * a * c;
+    if (!(disc > 0.0f)) return false;
+    float t1, t2;
+    int n = solve_quadratic(a, b, c, t1, t2);
+    if (n == 0) return false;
+    if (cylinder_ok(height, max_phi, r, t1, tmin, tmax)) { t_out = t1; return true; }
+    if (n == 2 && cylinder_ok(height, max_phi, r, t2, tmin, tmax)) { t_out = t2; return true; }
+    return false;
+}
+// objects/disk.rs:39-83
+__device__ __forceinline__ bool hit_disk(float radius, float phi_max, float inner_radius, const Ray &r, float tmin, float tmax, float &t_out) {
+    if (r.d.y == 0.f) return false;
+    float t = fdiv(-r.o.y, r.d.y);
+    if (t < tmin || t > tmax) return false;
+    V3 p = ray_point(r, t);
+    float dist2 = p.x * p.x + p.z * p.z;
+    if (dist2 > radius * radius || dist2 < inner_radius * inner_radius) return false;
+    float phi = atan2f(p.z, p.x);
+    if (phi < 0.f) phi = phi + 2.f * PI_F;
+    if (phi > phi_max) return false;
+    t_out = t;
+    return true;
+}
+
 // util.rs:104-118 — SIGNED comparison
 __device__ __forceinline__ int max_component_idx(V3 v) {
     if (v.x > v.y) return (v.z > v.x) ? 2 : 0;
@@ -399,6 +467,9 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
     case 1: case 2: case 3: return hit_rect_kind(kind, q3, q4.x, r, tmin, tmax, t);
     case 4: return hit_rect3d(q3, q4, r, tmin, tmax, t, prim);
     case 5: return hit_mesh(sc, aux0, aux1, r, tmin, tmax, stack_base, t, prim);
+    case 7: return hit_cone(q3.x, q3.y, r, tmin, tmax, t);
+    case 8: return hit_cylinder(q3.x, q3.y, q3.z, r, tmin, tmax, t);
+    case 9: return hit_disk(q3.x, q3.z, q3.w, r, tmin, tmax, t);
     default: return false;
     }
 }
@@ -582,7 +653,6 @@ __device__ __forceinline__ V3 texture_sample(const float4 *texp, const uint8_t *
     return mk(0.f, 0.f, 0.f);
 }
 
-constexpr float PI_F = 3.14159265358979323846f;
 __device__ __forceinline__ void sphere_uv(V3 p, float &u, float &v) {   // objects/sphere.rs:22-29
     float phi = atan2f(p.z, p.x);
     float theta = asinf(p.y);
@@ -675,6 +745,33 @@ __device__ __forceinline__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, c
         } else {
             h.v = b0 * 0.f + b1 * 0.f + b2 * 1.f;                                      // default uvs (mesh.rs:107)
             n = cross(p0 - p2, p1 - p2);                                               // unnormalised (mesh.rs:208)
+        }
+        break; }
+    case 7: {                                                                          // cone.rs:62-77
+        float radius = o.q3.x, height = o.q3.y;
+        float v = fdiv(p.y, height);
+        Rcp omv = make_rcp(1.f - v);
+        V3 dpdu = mk(-p.z, 0.f, p.x);
+        V3 dpdv = mk(fdiv(-p.x, omv), height, fdiv(-p.z, omv));
+        n = normalized(cross(dpdv, dpdu));
+        if (need_uv) { h.u = fdiv(acosf(fdiv(p.x, radius * (1.f - v))), 2.f * PI_F); h.v = v; }
+        break; }
+    case 8: {                                                                          // cylinder.rs:66-78
+        Rcp rr = make_rcp(o.q3.x);
+        n = mk(fdiv(p.x, rr), 0.f, fdiv(p.z, rr));
+        if (need_uv) {
+            float phi = atan2f(p.z, p.x);
+            if (phi < 0.f) phi = phi + PI_F * 2.f;
+            h.u = fdiv(phi, o.q3.z); h.v = fdiv(p.y, o.q3.y);
+        }
+        break; }
+    case 9: {                                                                          // disk.rs:60-82
+        if (need_uv) {
+            float phi = atan2f(p.z, p.x);
+            if (phi < 0.f) phi = phi + 2.f * PI_F;
+            h.u = fdiv(phi, o.q3.z);
+            float dist = fsqrt(p.x * p.x + p.z * p.z);
+            h.v = 1.f - fdiv(dist - o.q3.w, o.q3.x - o.q3.w);
         }
         break; }
     default: break;                                                                    // medium: normal +Y, uv 0 (volume.rs:72-78)

@@ -279,6 +279,14 @@ struct Flattener {
             sp.q3[0] = s.pos.x; sp.q3[1] = s.pos.y; sp.q3[2] = s.pos.z; sp.q3[3] = s.size.x; sp.q4[0] = s.size.y; sp.q4[1] = s.size.z;
             sp.box = {tov(s.pos), tov(s.pos) + tov(s.size)};
             return FW_OK;
+        case FW_SHAPE_CONE: case FW_SHAPE_CYLINDER:                 // cone.rs:90-95, cylinder.rs:92-97
+            sp.q3[0] = s.radius; sp.q3[1] = s.height; sp.q3[2] = s.phi_max;
+            sp.box = {{-s.radius, 0.f, -s.radius}, {s.radius, s.height, s.radius}};
+            return FW_OK;
+        case FW_SHAPE_DISK:                                          // disk.rs:85-90 — degenerate box, kept as written
+            sp.q3[0] = s.radius; sp.q3[2] = s.phi_max; sp.q3[3] = s.inner_radius;
+            sp.box = {{-s.radius, 0.f, s.radius}, {-s.radius, 0.001f, s.radius}};
+            return FW_OK;
         case FW_SHAPE_TRIANGLE_MESH: return mesh_params(s, sp);
         case FW_SHAPE_CONSTANT_MEDIUM: {                             // volume.rs:84-86: bbox of the inner shape
             if (nest > 0) return fail(FW_ERR_UNSUPPORTED, "ConstantMedium nested in a ConstantMedium");

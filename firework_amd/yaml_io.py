@@ -100,8 +100,12 @@ def _shape(d):
         return A.TriangleMesh(verts, np.array(d["indicies"], np.uint32), normals, uvs, int(d["material"]))
     if k == "ConstantMedium":
         return A.ConstantMedium(_shape(d["obj"]), float(d["density"]), int(d["material"]))
-    if k in ("Cone", "Cylinder", "Disk"):
-        raise UnsupportedShape(f"{k} (src/objects/{k.lower()}.rs) is not on the GPU path yet")
+    if k == "Cone":
+        return A.Cone(float(d["radius"]), float(d["height"]), int(d["material"]))
+    if k == "Cylinder":
+        return A.Cylinder(float(d["radius"]), float(d["height"]), int(d["material"]), float(d["max_phi"]))
+    if k == "Disk":
+        return A.Disk(float(d["radius"]), int(d["material"]), float(d["phi_max"]), float(d["inner_radius"]))
     raise ValueError(f"unknown object_type {k!r}")
 
 
@@ -180,6 +184,14 @@ def _rect_d(r):
 def _shape_d(s):
     if isinstance(s, A.Sphere):
         return {"object_type": "Sphere", "radius": float(s.radius), "material": int(s.material)}
+    if isinstance(s, A.Cone):
+        return {"object_type": "Cone", "radius": float(s.radius), "height": float(s.height), "material": int(s.material)}
+    if isinstance(s, A.Cylinder):
+        return {"object_type": "Cylinder", "radius": float(s.radius), "height": float(s.height), "max_phi": float(s.max_phi),
+                "material": int(s.material)}
+    if isinstance(s, A.Disk):
+        return {"object_type": "Disk", "radius": float(s.radius), "phi_max": float(s.phi_max),
+                "inner_radius": float(s.inner_radius), "material": int(s.material)}
     for name, cls in _RECTS.items():
         if isinstance(s, cls):
             return {"object_type": name, **_rect_d(s)}

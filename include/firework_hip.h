@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 1
+#define FW_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum fw_status {
@@ -102,13 +102,19 @@ typedef enum fw_shape_kind {
     FW_SHAPE_YZRECT = 3,          /*                          AARect<Y,Z>                   */
     FW_SHAPE_RECT3D = 4,          /* objects/rect3d.rs:9-86   {pos, size} + 6 derived faces */
     FW_SHAPE_TRIANGLE_MESH = 5,   /* objects/mesh.rs:12-63                                  */
-    FW_SHAPE_CONSTANT_MEDIUM = 6  /* objects/volume.rs:10-54  {obj, density, material}      */
+    FW_SHAPE_CONSTANT_MEDIUM = 6, /* objects/volume.rs:10-54  {obj, density, material}      */
+    FW_SHAPE_CONE = 7,            /* objects/cone.rs:9-25     {radius, height, material}    */
+    FW_SHAPE_CYLINDER = 8,        /* objects/cylinder.rs:10-38 {radius, height, max_phi, material} */
+    FW_SHAPE_DISK = 9             /* objects/disk.rs:10-37    {radius, phi_max, inner_radius, material} */
 } fw_shape_kind;
 
 typedef struct fw_shape {
     int32_t kind;
     int32_t material;          /* MaterialIdx (src/scene.rs:13) */
-    float radius;              /* Sphere */
+    float radius;              /* Sphere, Cone, Cylinder, Disk */
+    float height;              /* Cone, Cylinder */
+    float phi_max;             /* Cylinder.max_phi / Disk.phi_max, radians */
+    float inner_radius;        /* Disk */
     /* AARect<A1,A2>: min=(a_min,b_min) max=(a_max,b_max) on axes (A1,A2), plane at k
        on the third axis (rect.rs:14-20).  XY: a=x b=y; XZ: a=x b=z; YZ: a=y b=z. */
     float a_min, a_max, b_min, b_max, k;

@@ -225,6 +225,8 @@ struct Hitable {
     virtual AABB bounding_box() const = 0;
 };
 
+constexpr float PI_F = 3.14159265358979323846f;
+
 // objects/mod.rs:19-31
 inline int solve_quadratic(float a, float b, float c, float roots[2]) {
     float disc = b * b - 4.f * a * c;
@@ -234,8 +236,6 @@ inline int solve_quadratic(float a, float b, float c, float roots[2]) {
     roots[1] = (-b + std::sqrt(disc)) / (2.f * a);
     return 2;
 }
-
-constexpr float PI_F = 3.14159265358979323846f;
 
 // objects/sphere.rs:22-29
 inline void sphere_uv(V3 p, float &u, float &v) {
@@ -266,6 +266,92 @@ struct Sphere : Hitable {
         return true;
     }
     AABB bounding_box() const override { return {-(v3(1, 1, 1) * radius), v3(1, 1, 1) * radius}; }
+};
+
+// objects/cone.rs:9-96
+struct Cone : Hitable {
+    float radius, height; int material;
+    bool check(const Ray &r, float t, float tmin, float tmax, Hit &h) const {
+        if (t > tmax || t < tmin) return false;
+        V3 point = r.point(t);
+        if (point.y < 0.f || point.y > height) return false;
+        float v = point.y / height;
+        float phi = std::acos(point.x / (radius * (1.f - v)));
+        float u = phi / (2.f * PI_F);
+        V3 dpdu = v3(-point.z, 0.f, point.x);
+        V3 dpdv = v3(-point.x / (1.f - v), height, -point.z / (1.f - v));
+        h.t = t; h.point = point; h.normal = normalized(cross(dpdv, dpdu)); h.material = material; h.u = u; h.v = v;
+        return true;
+    }
+    bool hit(const Ray &r, float tmin, float tmax, Rng &, Hit &h) const override {
+        V3 o = r.o, d = r.d;
+        float r2_div_h2 = radius * radius / (height * height);
+        float a = d.x * d.x + d.z * d.z - r2_div_h2 * d.y * d.y;
+        float b = 2.f * (d.x * o.x + d.z * o.z - r2_div_h2 * d.y * (o.y - height));
+        float c = o.x * o.x + o.z * o.z - r2_div_h2 * (o.y - height) * (o.y - height);
+        float roots[2];
+        int n = solve_quadratic(a, b, c, roots);
+        if (n == 0) return false;
+        if (check(r, roots[0], tmin, tmax, h)) return true;
+        if (n == 2) return check(r, roots[1], tmin, tmax, h);
+        return false;
+    }
+    AABB bounding_box() const override { return {v3(-radius, 0.f, -radius), v3(radius, height, radius)}; }
+};
+
+// objects/cylinder.rs:10-98
+struct Cylinder : Hitable {
+    float radius, height, max_phi; int material;
+    bool check(const Ray &r, float t, float tmin, float tmax, Hit &h) const {
+        if (t > tmax || t < tmin) return false;
+        V3 point = r.point(t);
+        float phi = std::atan2(point.z, point.x);
+        if (phi < 0.f) phi = phi + PI_F * 2.f;
+        if (point.y > 0.f && point.y < height && phi < max_phi) {
+            h.t = t; h.point = point; h.normal = v3(point.x / radius, 0.f, point.z / radius); h.material = material;
+            h.u = phi / max_phi; h.v = point.y / height;
+            return true;
+        }
+        return false;
+    }
+    bool hit(const Ray &r, float tmin, float tmax, Rng &, Hit &h) const override {
+        V3 o = r.o, d = r.d;
+        float a = d.x * d.x + d.z * d.z;
+        float b = 2.f * (d.x * o.x + d.z * o.z);
+        float c = o.x * o.x + o.z * o.z - radius * radius;
+        float disc = b * b - 4.f * a * c;
+        if (disc > 0.0f) {
+            float roots[2];
+            int n = solve_quadratic(a, b, c, roots);
+            if (n == 0) return false;
+            if (check(r, roots[0], tmin, tmax, h)) return true;
+            if (n == 2) return check(r, roots[1], tmin, tmax, h);
+        }
+        return false;
+    }
+    AABB bounding_box() const override { return {v3(-radius, 0.f, -radius), v3(radius, height, radius)}; }
+};
+
+// objects/disk.rs:10-91
+struct Disk : Hitable {
+    float radius, phi_max, inner_radius; int material;
+    bool hit(const Ray &r, float tmin, float tmax, Rng &, Hit &h) const override {
+        if (r.d.y == 0.f) return false;
+        float t = -r.o.y / r.d.y;
+        if (t < tmin || t > tmax) return false;
+        V3 point = r.point(t);
+        float dist2 = point.x * point.x + point.z * point.z;
+        if (dist2 > radius * radius || dist2 < inner_radius * inner_radius) return false;
+        float phi = std::atan2(point.z, point.x);
+        if (phi < 0.f) phi = phi + 2.f * PI_F;
+        if (phi > phi_max) return false;
+        float dist = std::sqrt(dist2);
+        h.t = t; h.point = point; h.normal = v3(0, 1, 0); h.material = material;
+        h.u = phi / phi_max; h.v = 1.f - (dist - inner_radius) / (radius - inner_radius);
+        return true;
+    }
+    // degenerate in the reference (disk.rs:85-90): min = (-r, 0, +r), max = (-r, 0.001, +r) — kept as written
+    AABB bounding_box() const override { return {v3(-radius, 0.f, radius), v3(-radius, 0.001f, radius)}; }
 };
 
 // objects/rect.rs:13-86.  a1/a2 = the two in-plane axes, other = the plane's axis
@@ -709,6 +795,9 @@ std::unique_ptr<Hitable> make_shape(const fw_scene_desc *d, int32_t si, SceneInt
         chk_mat(s.material);
         return std::make_unique<AARect>(make_rect(s.kind, s.a_min, s.a_max, s.b_min, s.b_max, s.k, s.flip_normal != 0, s.material)); }
     case FW_SHAPE_RECT3D: chk_mat(s.material); return std::make_unique<Rect3d>(v3(s.pos), v3(s.size), s.material);
+    case FW_SHAPE_CONE: { chk_mat(s.material); auto p = std::make_unique<Cone>(); p->radius = s.radius; p->height = s.height; p->material = s.material; return p; }
+    case FW_SHAPE_CYLINDER: { chk_mat(s.material); auto p = std::make_unique<Cylinder>(); p->radius = s.radius; p->height = s.height; p->max_phi = s.phi_max; p->material = s.material; return p; }
+    case FW_SHAPE_DISK: { chk_mat(s.material); auto p = std::make_unique<Disk>(); p->radius = s.radius; p->phi_max = s.phi_max; p->inner_radius = s.inner_radius; p->material = s.material; return p; }
     case FW_SHAPE_TRIANGLE_MESH: {
         chk_mat(s.material);
         if (!s.verts || !s.indices || s.n_indices == 0 || s.n_indices % 3) throw BuildError{s.n_indices == 0 ? FW_ERR_EMPTY_SCENE : FW_ERR_BAD_ARG};

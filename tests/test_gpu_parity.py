@@ -130,6 +130,35 @@ def test_textures_and_smooth_normals(oracle):
         check(oracle, sc, r, max_bad_pixels=8)
 
 
+def test_conics(oracle):
+    """Cone / Cylinder (full and partial, inside + outside shells) / Disk (full and annular sector), image-textured
+    so that their uv code runs — examples/conics.rs restated at a closer camera.  With use_bvh the disks vanish,
+    exactly as in the reference: Disk::bounding_box is degenerate (disk.rs:85-90)."""
+    import math
+    from firework_amd.api import Cone, Cylinder, Disk
+    rng = np.random.default_rng(5)
+    sc = Scene.new()
+    img = (rng.random((32, 32, 3)) * 255).astype(np.uint8)
+    uvm = sc.add_material(LambertianMat.new(ImageTexture.new(img)))
+    blue = sc.add_material(LambertianMat.with_color((0.0, 0.2, 0.4)))
+    grey = sc.add_material(LambertianMat.with_color((0.5, 0.5, 0.5)))
+    light = sc.add_material(EmissiveMat.with_color((8.0, 8.0, 8.0)))
+    sc.add_object(RenderObject.new(Cylinder.new(2.0, 3.0, uvm)).position(-4.2, 0.0, 0.0))
+    sc.add_object(RenderObject.new(Disk.new(2.0, blue)).position(-4.2, 3.0, 0.0))
+    sc.add_object(RenderObject.new(Cone.new(2.0, 3.0, uvm)).position(-1.0, 0.0, -4.0))
+    rot = Rotor3.from_euler_angles(math.radians(90.0), math.radians(30.0), math.radians(-35.0))
+    sc.add_object(RenderObject.new(Cylinder.partial(1.5, 3.0, 300.0, uvm)).rotate(rot).position(3.0, 1.5, 1.0))
+    sc.add_object(RenderObject.new(Cylinder.partial(1.49, 3.0, 300.0, uvm)).rotate(rot).position(3.0, 1.5, 1.0).flip_normals())
+    sc.add_object(RenderObject.new(Disk.partial(1.5, 300.0, 0.8, uvm)).rotate(rot).position(3.0, 1.5, 1.0))
+    sc.add_object(RenderObject.new(XZRect.new(-100.0, 100.0, -100.0, 100.0, 0.0, grey)))
+    sc.add_object(RenderObject.new(YZRect.new(0.0, 20.0, 0.0, 10.0, -3.0, light)).rotate(Rotor3.from_rotation_xz(-30.0)).position(0.0, 0.0, -10.0))
+    sc.set_environment(SkyEnv.default())
+    cam = CameraSettings.default().cam_pos((0.0, 8.0, 14.0)).look_at((0.0, 1.0, 0.0)).field_of_view(40.0)
+    for bvh in (False, True):
+        r = Renderer.default().width(96).height(54).samples(16).use_bvh(bvh).camera(cam)
+        check(oracle, sc, r, max_bad_pixels=8)
+
+
 def test_medium_around_a_box_and_seed(oracle):
     sc = Scene.new()
     white = sc.add_material(LambertianMat.with_color((0.7, 0.7, 0.7)))

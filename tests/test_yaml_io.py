@@ -8,7 +8,7 @@ import yaml
 
 from firework_amd import scenes
 from firework_amd.api import Renderer
-from firework_amd.yaml_io import UnsupportedShape, load_scene, save_scene, scene_to_dict
+from firework_amd.yaml_io import load_scene, save_scene, scene_to_dict
 
 REF = "/root/reference"
 
@@ -69,6 +69,19 @@ def test_reads_reference_teapot_yml_with_vertex_normals(oracle):
 
 
 @pytest.mark.skipif(not os.path.exists(f"{REF}/scenes/conics.yml"), reason="reference tree not present")
-def test_conics_are_reported_not_misrendered():
-    with pytest.raises(UnsupportedShape):
-        load_scene(f"{REF}/scenes/conics.yml")
+def test_reads_reference_conics_yml(oracle):
+    """Cone / Cylinder / Disk + an ImageTexture named relative to the reference's working directory."""
+    sc = load_scene(f"{REF}/scenes/conics.yml")
+    kinds = [type(ro.obj).__name__ for ro in sc.render_objects]
+    assert kinds == ["Cylinder", "Disk", "Cone", "Cylinder", "Cylinder", "Disk", "XZRect", "YZRect"]
+    with open(f"{REF}/scenes/conics.yml") as f:
+        raw = yaml.load(f, Loader=getattr(yaml, "CSafeLoader", yaml.SafeLoader))
+    assert scene_to_dict(sc) == raw                      # writer reproduces the reference file's data
+    # constructors reproduce the serialised angles: Cylinder::partial(.., 300.) and Disk::new
+    from firework_amd.api import Cylinder, Disk
+    assert Cylinder.partial(1.5, 3.0, 300.0, 0).max_phi == raw["render_objects"][3]["obj"]["max_phi"]
+    assert Cylinder.new(2.0, 3.0, 0).max_phi == raw["render_objects"][0]["obj"]["max_phi"]
+    assert Disk.new(2.0, 1).phi_max == raw["render_objects"][1]["obj"]["phi_max"]
+    r = Renderer.default().width(32).height(18).samples(2)
+    img = oracle.render(sc, r)
+    assert np.isfinite(img.linear).all()
