@@ -72,6 +72,7 @@ struct DScene {
     const uint8_t *images;
     uint32_t n_objects;
     uint32_t has_medium;
+    uint32_t has_mesh;
     DEnv env;
 };
 
@@ -118,6 +119,7 @@ struct LaunchCfg {
     int tlas_depth, blas_depth;   // LDS traversal-stack levels needed
     uint32_t n_mat, n_tex;        // table sizes (for the LDS-resident copy in k_shade)
     bool lds_tables;              // stage small scene tables in LDS (debug switch: FIREWORK_NO_LDS_TABLES)
+    bool has_mesh;
 };
 constexpr size_t LDS_TABLE_LIMIT = 16 * 1024;   // object+material+texture tables up to this size are staged in LDS
 

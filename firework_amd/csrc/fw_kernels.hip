@@ -422,25 +422,34 @@ struct LdsStack {
 // tie) — the reference's winner in any visiting order and for any tree topology (the walked tree is SAH-built).  Differs only if the winning hit lies exactly on a culled
 // box's entry plane, or for NaN t.
 __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32_t tri_base, const Ray &r, float tmin,
-                                         float tmax, uint32_t *stack_base, float &t_out, uint32_t &tri_out) {
+                                         float tmax, float cull_t, uint32_t *stack_base, float &t_out, uint32_t &tri_out) {
     V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
     LdsStack st{stack_base, 0};
     bool have = false; float best = tmax; uint32_t best_tri = 0;
+    const uint32_t DONE = 0xffffffffu;
     uint32_t node = root;
-    for (;;) {
-        float4 lo = sc.blas[2 * (size_t)node], hi = sc.blas[2 * (size_t)node + 1];
-        if (hit_aabb(lo, hi, r.o, inv, tmin, have ? best : tmax)) {
+    while (node != DONE) {
+        // while-while: every lane first walks inner nodes until it holds a leaf (or runs out of tree); only then
+        // do the lanes test triangles, together — the long triangle test is not run for one or two lanes at a time
+        uint32_t leafA = 0, leafB = 0; bool got_leaf = false;
+        while (node != DONE) {
+            float4 lo = sc.blas[2 * (size_t)node], hi = sc.blas[2 * (size_t)node + 1];
+            // cull_t: a t the caller already holds from another object (hits beyond it cannot win; equal t still can)
+            bool hit = hit_aabb(lo, hi, r.o, inv, tmin, have ? fminf(best, cull_t) : cull_t);
             uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
-            uint32_t kind = A >> 30;
-            if (kind == 0) {
+            if (hit && (A >> 30) == 0u) {
                 bool left_first = comp(r.d, (int)(B & 3u)) >= 0.f;
                 uint32_t left = node + 1, right = A & NODE_MASK;
                 st.push(left_first ? right : left);
                 node = left_first ? left : right;
                 continue;
             }
-            uint32_t items[2] = {A & NODE_MASK, B};
-            int n_items = (kind == NODE_DOUBLE) ? 2 : 1;
+            node = st.sp ? st.pop() : DONE;
+            if (hit) { leafA = A; leafB = B; got_leaf = true; break; }
+        }
+        if (got_leaf) {
+            uint32_t items[2] = {leafA & NODE_MASK, leafB};
+            int n_items = ((leafA >> 30) == NODE_DOUBLE) ? 2 : 1;
             for (int q = 0; q < n_items; q++) {
                 const float4 *tp = sc.tri + 3 * (size_t)(tri_base + items[q]);
                 float4 a = tp[0], b = tp[1], c = tp[2];
@@ -451,8 +460,6 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
                 }
             }
         }
-        if (st.sp == 0) break;
-        node = st.pop();
     }
     t_out = best; tri_out = best_tri;
     return have;
@@ -466,7 +473,7 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
     case 0: return hit_sphere(q3.x, r, tmin, tmax, t);
     case 1: case 2: case 3: return hit_rect_kind(kind, q3, q4.x, r, tmin, tmax, t);
     case 4: return hit_rect3d(q3, q4, r, tmin, tmax, t, prim);
-    case 5: return hit_mesh(sc, aux0, aux1, r, tmin, tmax, stack_base, t, prim);
+    case 5: return hit_mesh(sc, aux0, aux1, r, tmin, tmax, tmax, stack_base, t, prim);
     case 7: return hit_cone(q3.x, q3.y, r, tmin, tmax, t);
     case 8: return hit_cylinder(q3.x, q3.y, q3.z, r, tmin, tmax, t);
     case 9: return hit_disk(q3.x, q3.z, q3.w, r, tmin, tmax, t);
@@ -508,15 +515,46 @@ __device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint3
 // ------------------------------------------------------------------------------------------------
 extern __shared__ uint32_t lds_stack[];
 
+// Deferred mesh work (k_extend<true>): most rays of a chunk miss a mesh's box while a few walk its BLAS
+// (rocprofv3 on suzanne: 14 % of lanes active).  A ray that reaches a mesh leaf of the TLAS does not enter the
+// BLAS; it parks (slot, mesh object, best hit so far) in a wave-private LDS list, and whenever 64 entries have
+// accumulated the whole wave walks BLASes together, one parked ray per lane, and writes the final hit records.
+constexpr uint32_t DEFER_CAP = 128;   // entries; a chunk adds at most 64, a flush removes 64
+
 template <bool USE_BVH>
 __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, float4 *__restrict__ hits,
-                                                  DQueue q, int segment, int tlas_levels) {
+                                                  DQueue q, int segment, int tlas_levels, int stack_levels) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     if (w >= q.n_waves) return;
     const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w];
     const uint32_t base = w * q.cap;
     uint32_t *my_stack = lds_stack + threadIdx.x;                    // [level][lane]
     uint32_t *blas_stack = my_stack + (size_t)tlas_levels * WB;      // BLAS levels sit above the TLAS levels
+    // deferred-mesh list (SoA) behind the stacks; WB == 64 when USE_BVH defers (one wave per workgroup)
+    uint32_t *e_slot = lds_stack + (size_t)stack_levels * WB, *e_obj = e_slot + DEFER_CAP, *e_bobj = e_obj + DEFER_CAP,
+             *e_bprim = e_bobj + DEFER_CAP;
+    float *e_t = reinterpret_cast<float *>(e_bprim + DEFER_CAP);
+    uint32_t list_n = 0;
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+
+    auto flush = [&](uint32_t first, uint32_t count) {               // entries [first, first+count), count <= 64
+        if (lane < count) {
+            const uint32_t e = first + lane;
+            const uint32_t slot = e_slot[e], obj = e_obj[e];
+            float bt = e_t[e]; uint32_t bobj = e_bobj[e], bprim = e_bprim[e];
+            float4 ra = in.ray_a[slot]; float2 rb = in.ray_b[slot];
+            Ray world{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
+            Obj o = load_obj(sc.obj, obj);
+            Ray r = to_object_space(o, world);
+            float t; uint32_t prim;
+            if (hit_mesh(sc, o.aux0, o.aux1, r, TMIN, TMAX, bt, blas_stack, t, prim)) {
+                if (bobj == MISS || t < bt || (t == bt && sc.obj_rank[obj] > sc.obj_rank[bobj])) { bt = t; bobj = obj; bprim = prim; }
+            }
+            hits[slot] = make_float4(bt, __uint_as_float(bobj), __uint_as_float(bprim), 0.f);
+        }
+    };
+
+    // software pipeline: the next chunk's ray is requested before the current chunk is traversed
     float4 ra_n = make_float4(0, 0, 0, 0); float2 rb_n = make_float2(0, 0);
     if (lane < n) { ra_n = in.ray_a[base + lane]; rb_n = in.ray_b[base + lane]; }
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
@@ -524,53 +562,69 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
         const uint32_t i = base + j;
         float4 ra = ra_n; float2 rb = rb_n;
         if (j + 64u < n) { ra_n = in.ray_a[i + 64u]; rb_n = in.ray_b[i + 64u]; }
-        if (j >= n) continue;
-        Ray r{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
-        RngKey key{0, 0, 0};
-        if (sc.has_medium) key = key_of(f, __float_as_uint(in.state[i].w));
-        const float TMIN = 0.001f, TMAX = 2e9f;                      // render.rs:19
+        const bool active = j < n;
+        bool deferred = false; uint32_t deferred_obj = 0;
         float best_t = TMAX; uint32_t best_obj = MISS, best_prim = 0;
-        if (!USE_BVH) {
-            // scene.rs:137-149: linear scan with narrowing; a later object replaces on t <= closest
-            for (uint32_t j = 0; j < sc.n_objects; j++) {
-                Obj o = load_obj(sc.obj, j);     // wave-uniform index: scalar loads
-                float t; uint32_t prim;
-                if (hit_object(sc, o, j, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = j; best_prim = prim; }
-            }
-        } else {
-            // bvh.rs:88-98,115-151 over RenderObjectInternal items; same front-to-back scheme as hit_mesh
-            V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
-            LdsStack st{my_stack, 0};
-            bool have = false;
-            uint32_t node = 0;
-            for (;;) {
-                float4 lo = sc.tlas[2 * (size_t)node], hi = sc.tlas[2 * (size_t)node + 1];
-                if (hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX)) {
-                    uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
-                    uint32_t kind = A >> 30;
-                    if (kind == 0) {
-                        bool left_first = comp(r.d, (int)(B & 3u)) >= 0.f;
-                        uint32_t left = node + 1, right = A & NODE_MASK;
-                        st.push(left_first ? right : left);
-                        node = left_first ? left : right;
-                        continue;
-                    }
-                    uint32_t items[2] = {A & NODE_MASK, B};
-                    int n_items = (kind == NODE_DOUBLE) ? 2 : 1;
-                    for (int q = 0; q < n_items; q++) {
-                        Obj o = load_obj(sc.obj, items[q]);
-                        float t; uint32_t prim;
-                        if (hit_object(sc, o, items[q], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
-                            if (!have || t < best_t || (t == best_t && sc.obj_rank[items[q]] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = items[q]; best_prim = prim; }
+        if (active) {
+            Ray r{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
+            RngKey key{0, 0, 0};
+            if (sc.has_medium) key = key_of(f, __float_as_uint(in.state[i].w));
+            if (!USE_BVH) {
+                // scene.rs:137-149: linear scan with narrowing; a later object replaces on t <= closest
+                for (uint32_t k = 0; k < sc.n_objects; k++) {
+                    Obj o = load_obj(sc.obj, k);     // wave-uniform index: scalar loads
+                    float t; uint32_t prim;
+                    if (hit_object(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+                }
+            } else {
+                // bvh.rs:88-98,115-151 over RenderObjectInternal items; same front-to-back scheme as hit_mesh
+                V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                LdsStack st{my_stack, 0};
+                bool have = false;
+                uint32_t node = 0;
+                for (;;) {
+                    float4 lo = sc.tlas[2 * (size_t)node], hi = sc.tlas[2 * (size_t)node + 1];
+                    if (hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX)) {
+                        uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
+                        uint32_t kind = A >> 30;
+                        if (kind == 0) {
+                            bool left_first = comp(r.d, (int)(B & 3u)) >= 0.f;
+                            uint32_t left = node + 1, right = A & NODE_MASK;
+                            st.push(left_first ? right : left);
+                            node = left_first ? left : right;
+                            continue;
+                        }
+                        uint32_t items[2] = {A & NODE_MASK, B};
+                        int n_items = (kind == NODE_DOUBLE) ? 2 : 1;
+                        for (int qq = 0; qq < n_items; qq++) {
+                            Obj o = load_obj(sc.obj, items[qq]);
+                            if (sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = items[qq]; continue; }   // park the first mesh
+                            float t; uint32_t prim;
+                            if (hit_object(sc, o, items[qq], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+                                if (!have || t < best_t || (t == best_t && sc.obj_rank[items[qq]] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = items[qq]; best_prim = prim; }
+                            }
                         }
                     }
+                    if (st.sp == 0) break;
+                    node = st.pop();
                 }
-                if (st.sp == 0) break;
-                node = st.pop();
+            }
+            if (!deferred) hits[i] = make_float4(best_t, __uint_as_float(best_obj), __uint_as_float(best_prim), 0.f);
+        }
+        if (USE_BVH && sc.has_mesh) {
+            unsigned long long mask = __ballot(deferred);
+            if (mask) {
+                uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (deferred) {
+                    uint32_t e = list_n + rank;
+                    e_slot[e] = i; e_obj[e] = deferred_obj; e_t[e] = best_t; e_bobj[e] = best_obj; e_bprim[e] = best_prim;
+                }
+                list_n += (uint32_t)__popcll(mask);
+                if (list_n >= 64u) { list_n -= 64u; flush(list_n, 64u); }
             }
         }
-        hits[i] = make_float4(best_t, __uint_as_float(best_obj), __uint_as_float(best_prim), 0.f);
     }
+    if (USE_BVH && list_n) flush(0u, list_n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -976,10 +1030,11 @@ void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPat
 }
 void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float4 *hits, int segment, bool use_bvh) {
     int tl = use_bvh ? c.tlas_depth + 1 : 0;
-    size_t lds = (size_t)(tl + c.blas_depth + 1) * WB * sizeof(uint32_t);
+    int levels = tl + c.blas_depth + 1;
+    size_t lds = (size_t)levels * WB * sizeof(uint32_t) + (use_bvh && c.has_mesh ? 5 * DEFER_CAP * sizeof(uint32_t) : 0);
     dim3 eg = wave_grid(c);
-    if (use_bvh) hipLaunchKernelGGL(k_extend<true>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl);
-    else hipLaunchKernelGGL(k_extend<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl);
+    if (use_bvh) hipLaunchKernelGGL(k_extend<true>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+    else hipLaunchKernelGGL(k_extend<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float4 *hits,
                   float4 *sample_rad, int segment) {

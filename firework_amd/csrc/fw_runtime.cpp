@@ -490,7 +490,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.tri = (const float4 *)sc->tri.p; d.tri_nrm = (const float4 *)sc->tri_attr.p;
     d.tri_rank = (const uint32_t *)sc->tri_rank.p; d.obj_rank = (const uint32_t *)sc->obj_rank.p;
     d.mat = (const float4 *)sc->mat.p; d.tex = (const float4 *)sc->tex.p; d.images = (const uint8_t *)sc->images.p;
-    d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u;
+    d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
     d.env.kind = e.kind;
     d.env.color[0] = e.color.x; d.env.color[1] = e.color.y; d.env.color[2] = e.color.z;
     d.env.zenith[0] = e.zenith.x; d.env.zenith[1] = e.zenith.y; d.env.zenith[2] = e.zenith.z;
@@ -599,6 +599,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.tlas_depth = (int)sc->tlas_depth; cfg.blas_depth = (int)sc->blas_depth;
     cfg.n_mat = sc->n_mat; cfg.n_tex = sc->n_tex;
     cfg.lds_tables = getenv("FIREWORK_NO_LDS_TABLES") == nullptr;
+    cfg.has_mesh = sc->d.has_mesh != 0;
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
@@ -673,6 +674,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         }
         stats->n_extend_launches = n_batches * fw::MAX_SEGMENTS; stats->n_shade_launches = n_batches * fw::MAX_SEGMENTS;
         stats->n_batches = n_batches; stats->tlas_nodes = sc->tlas_nodes; stats->blas_nodes = sc->blas_nodes;
+        stats->reserved = (sc->tlas_depth << 16) | sc->blas_depth;   // depths of the trees actually walked
     }
     return FW_OK;
 }
