@@ -465,7 +465,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     if (e.kind == FW_ENV_HDR && (!e.hdr_rgb || !e.hdr_w || !e.hdr_h)) return fail(FW_ERR_BAD_ARG, "HdrEnv without pixels");
 
     // stack depth the kernels will be given
-    if (tlas.depth + 1 + fl.blas_depth + 1 > 60) return fail(FW_ERR_BVH_DEPTH, "BVH deeper than the LDS traversal stack (60 levels)");
+    if (tlas.depth + 1 + fl.blas_depth + 1 > 120) return fail(FW_ERR_BVH_DEPTH, "BVH deeper than the LDS traversal stack (120 levels)");
 
     fw_scene *sc = new (std::nothrow) fw_scene();
     if (!sc) return fail(FW_ERR_OOM, "host allocation failed");

@@ -1,0 +1,40 @@
+"""Committed golden vectors (tests/golden/oracle_*.npz, made by scripts/make_oracle_goldens.py from the CPU oracle):
+the oracle must keep reproducing them (CPU), and the HIP path must match them directly (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from make_oracle_goldens import CASES, build  # noqa: E402
+
+NAMES = list(CASES) + ["C4a_hdri_test"]
+
+
+def _load(name):
+    return np.load(os.path.join(ROOT, "tests", "golden", f"oracle_{name}.npz"))
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_goldens(oracle, name):
+    g = _load(name)
+    s, r = build(name)
+    res = oracle.render(s, r)
+    assert np.array_equal(res.rgb8, g["rgb8"])
+    assert np.allclose(res.linear, g["linear"], rtol=1e-6, atol=1e-7)      # same binary -> equal; libm may differ across hosts
+    assert list(res.stats["rays_per_depth"]) == [int(x) for x in g["rays_per_depth"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_matches_goldens(name):
+    g = _load(name)
+    s, r = build(name)
+    res = r.render_full(s)
+    gam = lambda lin: np.clip(np.nan_to_num(lin, nan=0.0) ** (1 / 2.2), 0, 1)
+    rms = float(np.sqrt(np.mean((gam(res.linear.astype(np.float64)) - gam(g["linear"].astype(np.float64))) ** 2)))
+    assert rms <= 1e-3, rms                                                   # north-star gate
+    assert (res.rgb8 != g["rgb8"]).sum() <= 6
+    assert abs(int(res.stats["rays"]) - int(g["rays_per_depth"].sum())) <= 40

@@ -199,6 +199,58 @@ def test_errors_cross_the_abi_as_codes():
     assert e.value.status == A.FW_ERR_BAD_ARG
 
 
+def test_error_codes_match_between_oracle_and_gpu(oracle):
+    """Malformed inputs: same status from the HIP library and the oracle (the reference panics in these places)."""
+    from firework_amd import _abi as A
+    r = Renderer.default().width(8).height(8).samples(1)
+
+    def status_gpu(scene, **kw):
+        try:
+            r.render_full(scene, **kw)
+            return 0
+        except _lib.FireworkError as e:
+            return e.status
+
+    def status_cpu(scene, **kw):
+        try:
+            oracle.render(scene, r, **kw)
+            return 0
+        except oracle.OracleError as e:
+            return e.status
+
+    # NaN position -> NaN bounding-box centre -> bvh.rs:34 "Float comparison failed in BVH constructor"
+    sc = Scene.new()
+    m = sc.add_material(LambertianMat.with_color((0.5, 0.5, 0.5)))
+    sc.add_object(RenderObject.new(Sphere.new(1.0, m)).position(float("nan"), 0.0, 0.0))
+    sc.add_object(RenderObject.new(Sphere.new(1.0, m)).position(2.0, 0.0, 0.0))
+    sc.add_object(RenderObject.new(Sphere.new(1.0, m)).position(4.0, 0.0, 0.0))
+    assert status_gpu(sc) == A.FW_ERR_NAN_BBOX
+    r.use_bvh(True)
+    assert status_cpu(sc) == A.FW_ERR_NAN_BBOX
+    r.use_bvh(False)
+    # material index out of range
+    sc = Scene.new()
+    sc.add_object(RenderObject.new(Sphere.new(1.0, 3)))
+    assert status_gpu(sc) == status_cpu(sc) == A.FW_ERR_BAD_ARG
+    # vertex index out of range
+    sc = Scene.new()
+    m = sc.add_material(LambertianMat.with_color((0.5, 0.5, 0.5)))
+    sc.add_object(RenderObject.new(TriangleMesh.new(np.zeros((3, 3), np.float32), [0, 1, 7], None, None, m)))
+    assert status_gpu(sc) == status_cpu(sc) == A.FW_ERR_BAD_ARG
+    # pixel id outside the image
+    s2, _ = scenes.cornell_box()
+    assert status_gpu(s2, pixel_ids=np.array([0, 64], np.uint32)) == status_cpu(s2, pixel_ids=np.array([0, 64], np.uint32)) == A.FW_ERR_BAD_ARG
+
+
+def test_ragged_sizes_and_single_pixel(oracle):
+    """Non-multiple-of-64 path counts, 1x1 image, 1 spp, more pixels than pool slots."""
+    s, _ = scenes.cornell_box()
+    cam = CameraSettings.default().cam_pos((278.0, 278.0, -800.0)).look_at((278.0, 278.0, 0.0)).field_of_view(40.0)
+    for (w, h, spp, ppb) in [(1, 1, 1, 0), (7, 3, 5, 0), (33, 17, 3, 100), (65, 1, 129, 4096)]:
+        r = Renderer.default().width(w).height(h).samples(spp).camera(cam).paths_per_batch(ppb)
+        check(oracle, s, r)
+
+
 def test_full_size_properties_cornell():
     """At BASELINE's full size (512x512; spp reduced to keep the test short) check size-independent
     properties instead of the oracle: determinism, ray accounting, and the estimator's linearity in spp."""
