@@ -255,13 +255,16 @@ template <int AX>
 __device__ __forceinline__ bool hit_rect(float a_min, float a_max, float b_min, float b_max, float k, const Ray &r,
                                          float tmin, float tmax, float &t_out) {
     constexpr int A1 = (AX == 2) ? 1 : 0, A2 = (AX == 0) ? 1 : 2, OT = (AX == 0) ? 2 : (AX == 1 ? 1 : 0);
+    // rect.rs:47-62 as ONE comparison: the six range tests `x < lo || x > hi` are signs of exact differences
+    // (x - lo < 0 iff x < lo in IEEE arithmetic with denormals), so the hit is `min of the six slacks >= 0`.
+    // fminf drops NaNs just as the reference's comparisons are all false on them.  Why: 18 of these run per
+    // cornell ray, and six v_cmp + five s_or_b64 each kept the CU's single scalar unit ~80 % busy (rocprofv3:
+    // 466 SALU vs 603 VALU instructions per wave-chunk); min3 chains stay on the vector pipes.
     float t = fdiv(k - comp(r.o, OT), comp(r.d, OT));
-    if (t < tmin || t > tmax) return false;
-    V3 p = ray_point(r, t);
-    float pa = comp(p, A1), pb = comp(p, A2);
-    if (pa < a_min || pa > a_max || pb < b_min || pb > b_max) return false;
+    float pa = comp(r.o, A1) + t * comp(r.d, A1), pb = comp(r.o, A2) + t * comp(r.d, A2);
+    float slack = fminf(fminf(fminf(t - tmin, tmax - t), fminf(pa - a_min, a_max - pa)), fminf(pb - b_min, b_max - pb));
     t_out = t;
-    return true;
+    return !(slack < 0.f);
 }
 __device__ __forceinline__ bool hit_rect_kind(uint32_t kind, float4 q3, float k, const Ray &r, float tmin, float tmax, float &t) {
     if (kind == 1) return hit_rect<0>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
@@ -273,7 +276,7 @@ __device__ __forceinline__ bool hit_rect_kind(uint32_t kind, float4 q3, float k,
 __device__ __forceinline__ bool hit_rect3d(float4 q3, float4 q4, const Ray &r, float tmin, float tmax, float &t_out, uint32_t &face) {
     float px = q3.x, py = q3.y, pz = q3.z, sx = q3.w, sy = q4.x, sz = q4.y;
     bool any = false; float closest = tmax, t; face = 0;
-    bool h;
+    bool h;   // predicated: no exec-mask bookkeeping between the six faces
     h = hit_rect<0>(px, px + sx, py, py + sy, pz + sz, r, tmin, closest, t); closest = h ? t : closest; face = h ? 0u : face; any |= h;
     h = hit_rect<0>(px, px + sx, py, py + sy, pz, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 1u : face; any |= h;
     h = hit_rect<1>(px, px + sx, pz, pz + sz, py + sy, r, tmin, closest, t); closest = h ? t : closest; face = h ? 2u : face; any |= h;
