@@ -950,16 +950,16 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
 }
 
-// per-segment queue totals of one batch (ray statistics): totals[s] = sum_w wcount[s][w]
+// per-segment queue totals of one batch (ray statistics): totals[s] += sum_w wcount[s][w]; grid = (slices, segments)
 __global__ __launch_bounds__(BLOCK) void k_queue_totals(DQueue q, uint32_t *totals) {
     __shared__ uint32_t part[BLOCK];
-    const uint32_t seg = blockIdx.x;
+    const uint32_t seg = blockIdx.y;
     uint32_t acc = 0;
-    for (uint32_t w = threadIdx.x; w < q.n_waves; w += BLOCK) acc += q.wcount[(size_t)seg * q.n_waves + w];
+    for (uint32_t w = blockIdx.x * BLOCK + threadIdx.x; w < q.n_waves; w += gridDim.x * BLOCK) acc += q.wcount[(size_t)seg * q.n_waves + w];
     part[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s2 = BLOCK / 2; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2]; __syncthreads(); }
-    if (threadIdx.x == 0) totals[seg] = part[0];
+    if (threadIdx.x == 0 && part[0]) atomicAdd(&totals[seg], part[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1048,7 +1048,7 @@ void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths 
         hipLaunchKernelGGL(k_shade<false>, wave_grid(c), dim3(WB), 0, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
 }
 void launch_queue_totals(const LaunchCfg &c, uint32_t *totals) {
-    hipLaunchKernelGGL(k_queue_totals, dim3(MAX_SEGMENTS), dim3(BLOCK), 0, c.stream, c.q, totals);
+    hipLaunchKernelGGL(k_queue_totals, dim3(32, MAX_SEGMENTS), dim3(BLOCK), 0, c.stream, c.q, totals);   // totals are zeroed per frame
 }
 void launch_accumulate(const LaunchCfg &c, const DFrame &f, const float4 *sample_rad, float4 *accum) {
     hipLaunchKernelGGL(k_accumulate, dim3(c.blocks_other), dim3(BLOCK), 0, c.stream, f, sample_rad, accum);
