@@ -8,7 +8,7 @@ SRC = firework_amd/csrc/fw_kernels.hip firework_amd/csrc/fw_runtime.cpp
 HDR = firework_amd/csrc/fw_device.h include/firework_hip.h
 LIB = firework_amd/lib/libfirework_hip.so
 
-all: $(LIB) oracle
+all: $(LIB) oracle examples
 
 $(LIB): $(SRC) $(HDR)
 	mkdir -p firework_amd/lib
@@ -17,8 +17,14 @@ $(LIB): $(SRC) $(HDR)
 oracle:
 	$(MAKE) -C oracle
 
+# C++ host-side mirror of the reference API (include/firework.hpp): plain g++, links the C ABI only
+examples: examples/cornell_box
+
+examples/cornell_box: examples/cornell_box.cpp include/firework.hpp include/firework_hip.h $(LIB)
+	g++ -O2 -std=c++17 -Iinclude -o $@ examples/cornell_box.cpp -Lfirework_amd/lib -lfirework_hip -Wl,-rpath,'$$ORIGIN/../firework_amd/lib'
+
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) examples/cornell_box
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle examples clean

@@ -269,6 +269,11 @@ class Sphere(Shape):
 _RADS_PER_DEG = F32(F32(math.pi) / F32(180.0))     # f32::to_radians: self * (PI / 180)
 
 
+def to_radians(deg) -> float:
+    """Rust `f32::to_radians` (the examples write `18_f32.to_radians()`): one f32 multiply by PI/180."""
+    return float(F32(deg) * _RADS_PER_DEG)
+
+
 @dataclass
 class Cone(Shape):
     """src/objects/cone.rs:9-25"""

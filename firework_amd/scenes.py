@@ -11,7 +11,7 @@ import numpy as np
 
 from .api import (CameraSettings, CheckerTexture, ConstantTexture, DielectricMat, EmissiveMat, HdrEnvironment,
                   ImageTexture, LambertianMat, MetalMat, Rect3d, RenderObject, Renderer, Rotor3, Scene, SkyEnv,
-                  Sphere, TriangleMesh, TurbulenceTexture, XYRect, XZRect, YZRect)
+                  Sphere, TriangleMesh, TurbulenceTexture, XYRect, XZRect, YZRect, to_radians)
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCENES_DIR = os.path.join(_ROOT, "scenes")
@@ -44,10 +44,10 @@ def cornell_box():
     world.add_object(RenderObject.new(XZRect.new(0.0, 555.0, 0.0, 555.0, 555.0, white)).flip_normals())
     world.add_object(RenderObject.new(XYRect.new(0.0, 555.0, 0.0, 555.0, 555.0, white)).flip_normals())
     world.add_object(RenderObject.new(Rect3d.with_size((165.0, 165.0, 165.0), white))
-                     .rotate(Rotor3.from_rotation_xz(np.float32(math.radians(18.0))))
+                     .rotate(Rotor3.from_rotation_xz(to_radians(18.0)))
                      .position(130.0, 0.0, 65.0))
     world.add_object(RenderObject.new(Rect3d.with_size((165.0, 330.0, 165.0), white))
-                     .rotate(Rotor3.from_rotation_xz(np.float32(math.radians(-15.0))))
+                     .rotate(Rotor3.from_rotation_xz(to_radians(-15.0)))
                      .position(265.0, 0.0, 295.0))
     camera = CameraSettings.default().cam_pos((278.0, 278.0, -800.0)).look_at((278.0, 278.0, 0.0)).field_of_view(40.0)
     renderer = Renderer.default().width(300).height(300).samples(1000).camera(camera)
