@@ -9,11 +9,11 @@ namespace fw {
 // ---- object record: 6 x float4 = 96 B, 16-B aligned (one RenderObjectInternal, scene.rs:165-174,
 //      with its shape inlined).  Linear scenes read it with a wave-uniform index (scalar loads),
 //      TLAS leaves with a per-lane index (float4 vector loads).
-//   q0 = (R00 R01 R02 pos.x)   rows of rotation_mat, translation in .w
-//   q1 = (R10 R11 R12 pos.y)   (inv_rotation_mat is exactly the transpose: scene.rs:285)
-//   q2 = (R20 R21 R22 pos.z)
-//   q3, q4 = shape parameters (below)
-//   q5 = (bits: kind | flags<<8 | inner_kind<<24, bits: material, bits: aux0, bits: aux1)
+//   r0 = (pos.xyz, bits: kind | flags<<8 | inner_kind<<24)      <- all an unrotated sphere needs with r1
+//   r1 = q3, r2 = q4 = shape parameters (below)
+//   r3 = (R00 R01 R02, bits material)   rows of rotation_mat (inv_rotation_mat is exactly the transpose:
+//   r4 = (R10 R11 R12, bits aux0)        scene.rs:285)
+//   r5 = (R20 R21 R22, bits aux1)
 constexpr int OBJ_Q = 6;
 
 enum : uint32_t {

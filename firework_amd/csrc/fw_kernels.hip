@@ -200,13 +200,34 @@ __global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out
 // ------------------------------------------------------------------------------------------------
 struct Obj { float4 q0, q1, q2, q3, q4; uint32_t kf, material, aux0, aux1; };
 
+// record layout (fw_device.h): r0 = (pos.xyz, kind|flags) r1 = q3 r2 = q4 r3..r5 = (R row i, material | aux0 | aux1)
 __device__ __forceinline__ Obj load_obj(const float4 *__restrict__ objs, uint32_t j) {
     const float4 *p = objs + (size_t)j * OBJ_Q;
+    float4 r0 = p[0], r3 = p[3], r4 = p[4], r5 = p[5];
     Obj o;
-    o.q0 = p[0]; o.q1 = p[1]; o.q2 = p[2]; o.q3 = p[3]; o.q4 = p[4];
-    float4 q5 = p[5];
-    o.kf = __float_as_uint(q5.x); o.material = __float_as_uint(q5.y);
-    o.aux0 = __float_as_uint(q5.z); o.aux1 = __float_as_uint(q5.w);
+    o.q0 = make_float4(r3.x, r3.y, r3.z, r0.x); o.q1 = make_float4(r4.x, r4.y, r4.z, r0.y); o.q2 = make_float4(r5.x, r5.y, r5.z, r0.z);
+    o.q3 = p[1]; o.q4 = p[2];
+    o.kf = __float_as_uint(r0.w); o.material = __float_as_uint(r3.w);
+    o.aux0 = __float_as_uint(r4.w); o.aux1 = __float_as_uint(r5.w);
+    return o;
+}
+// Per-lane (TLAS leaf) fetch for k_extend: only what the intersection needs.  An unrotated sphere costs two
+// 16-byte loads instead of six — these divergent gathers, not arithmetic, bound the BVH scenes (64 B/clk/CU).
+__device__ __forceinline__ Obj load_obj_for_hit(const float4 *__restrict__ objs, uint32_t j) {
+    const float4 *p = objs + (size_t)j * OBJ_Q;
+    float4 r0 = p[0];
+    Obj o;
+    o.kf = __float_as_uint(r0.w); o.material = 0; o.aux0 = 0; o.aux1 = 0;
+    o.q0 = make_float4(1.f, 0.f, 0.f, r0.x); o.q1 = make_float4(0.f, 1.f, 0.f, r0.y); o.q2 = make_float4(0.f, 0.f, 1.f, r0.z);
+    o.q3 = p[1]; o.q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t kind = o.kf & 0xffu, flags = (o.kf >> 8) & 0xffffu, inner = o.kf >> 24;
+    if (kind == 1u || kind == 2u || kind == 3u || kind == 4u || kind == 6u) o.q4 = p[2];
+    const bool mesh = kind == 5u || (kind == 6u && inner == 5u);
+    if ((flags & OF_ROTATED) || mesh) {
+        float4 r3 = p[3], r4 = p[4], r5 = p[5];
+        o.q0 = make_float4(r3.x, r3.y, r3.z, r0.x); o.q1 = make_float4(r4.x, r4.y, r4.z, r0.y); o.q2 = make_float4(r5.x, r5.y, r5.z, r0.z);
+        o.aux0 = __float_as_uint(r4.w); o.aux1 = __float_as_uint(r5.w);
+    }
     return o;
 }
 __device__ __forceinline__ uint32_t obj_kind(const Obj &o) { return o.kf & 0xffu; }
@@ -584,23 +605,31 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
                 V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
                 LdsStack st{my_stack, 0};
                 bool have = false;
+                const uint32_t DONE = 0xffffffffu;
                 uint32_t node = 0;
-                for (;;) {
-                    float4 lo = sc.tlas[2 * (size_t)node], hi = sc.tlas[2 * (size_t)node + 1];
-                    if (hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX)) {
+                while (node != DONE) {
+                    // while-while: walk inner nodes until this lane holds a leaf (or is out of tree); the lanes then
+                    // run their object tests together (part2: 21 % of lanes were active in the interleaved form)
+                    uint32_t leafA = 0, leafB = 0; bool got_leaf = false;
+                    while (node != DONE) {
+                        float4 lo = sc.tlas[2 * (size_t)node], hi = sc.tlas[2 * (size_t)node + 1];
+                        bool hitb = hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX);
                         uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
-                        uint32_t kind = A >> 30;
-                        if (kind == 0) {
+                        if (hitb && (A >> 30) == 0u) {
                             bool left_first = comp(r.d, (int)(B & 3u)) >= 0.f;
                             uint32_t left = node + 1, right = A & NODE_MASK;
                             st.push(left_first ? right : left);
                             node = left_first ? left : right;
                             continue;
                         }
-                        uint32_t items[2] = {A & NODE_MASK, B};
-                        int n_items = (kind == NODE_DOUBLE) ? 2 : 1;
+                        node = st.sp ? st.pop() : DONE;
+                        if (hitb) { leafA = A; leafB = B; got_leaf = true; break; }
+                    }
+                    if (got_leaf) {
+                        uint32_t items[2] = {leafA & NODE_MASK, leafB};
+                        int n_items = ((leafA >> 30) == NODE_DOUBLE) ? 2 : 1;
                         for (int qq = 0; qq < n_items; qq++) {
-                            Obj o = load_obj(sc.obj, items[qq]);
+                            Obj o = load_obj_for_hit(sc.obj, items[qq]);
                             if (sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = items[qq]; continue; }   // park the first mesh
                             float t; uint32_t prim;
                             if (hit_object(sc, o, items[qq], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
@@ -608,8 +637,6 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
                             }
                         }
                     }
-                    if (st.sp == 0) break;
-                    node = st.pop();
                 }
             }
             if (!deferred) hits[i] = make_float4(best_t, __uint_as_float(best_obj), __uint_as_float(best_prim), 0.f);

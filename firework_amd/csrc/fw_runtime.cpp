@@ -402,13 +402,11 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         int32_t material = desc->shapes[o.shape].material;
         float *q = &objs[(size_t)i * fw::OBJ_Q * 4];
         const float pos[3] = {o.position.x, o.position.y, o.position.z};
-        for (int r = 0; r < 3; r++) { q[4 * r] = rows[r][0]; q[4 * r + 1] = rows[r][1]; q[4 * r + 2] = rows[r][2]; q[4 * r + 3] = pos[r]; }
-        std::memcpy(q + 12, sp.q3, 16);
-        std::memcpy(q + 16, sp.q4, 16);
-        q[20] = bits_f(kind | (flags << 8) | (inner << 24));
-        q[21] = bits_f((uint32_t)material);
-        q[22] = bits_f(sp.aux0);
-        q[23] = bits_f(sp.aux1);
+        q[0] = pos[0]; q[1] = pos[1]; q[2] = pos[2]; q[3] = bits_f(kind | (flags << 8) | (inner << 24));
+        std::memcpy(q + 4, sp.q3, 16);
+        std::memcpy(q + 8, sp.q4, 16);
+        const uint32_t tail[3] = {(uint32_t)material, sp.aux0, sp.aux1};
+        for (int r = 0; r < 3; r++) { q[12 + 4 * r] = rows[r][0]; q[13 + 4 * r] = rows[r][1]; q[14 + 4 * r] = rows[r][2]; q[15 + 4 * r] = bits_f(tail[r]); }
     }
     FlatBvh tlas;
     try { bvh_build(tlas, world); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }

@@ -1,11 +1,8 @@
 R=$PWD
 run() {
-  python3 $R/bench.py --config $1 --steps 1 --warmup 1 --no-cpu-baseline $2 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('kernel_ms_per_step',{}); print('$1 $2 $FIREWORK_BVH', 'Mrays/s', round(d['value']), 'Msamples/s', round(d['msamples_per_s']), 'ms', round(d['ms_per_step'],1), 'rays/sample', round(d['rays_per_sample'],2), 'ext', round(k.get('ms_extend',0),1), 'shd', round(k.get('ms_shade',0),1))"
+  python3 $R/bench.py --config $1 --steps 2 --warmup 1 --no-cpu-baseline $2 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('kernel_ms_per_step',{}); print('$1 $2', 'Mrays/s', round(d['value']), 'Msamples/s', round(d['msamples_per_s']), 'ms', round(d['ms_per_step'],1), 'rays/sample', round(d['rays_per_sample'],2), 'ext', round(k.get('ms_extend',0),1), 'shd', round(k.get('ms_shade',0),1))"
 }
+run C1_random_spheres
 run C3_suzanne
 run C5_part2_all "--spp 256"
-python3 -c "
-from firework_amd import scenes
-for c in ('C3_suzanne','C5_part2_all','C1_random_spheres'):
-    s,r = scenes.config(c, 64, 36, 1); st = r.render_full(s).stats; print(c, 'tlas_depth', st['reserved']>>16, 'blas_depth', st['reserved']&0xffff, st['tlas_nodes'], st['blas_nodes'])
-"
+run C2_cornell_box
