@@ -270,3 +270,23 @@ def test_full_size_properties_cornell():
     assert h.stats["rays"] < st["rays"]
     m = float(np.mean(a.linear)), float(np.mean(h.linear))
     assert abs(m[0] - m[1]) / m[0] < 0.05
+
+
+@pytest.mark.parametrize("name,spp", [("C3_suzanne", 4), ("C4a_hdri_test", 4), ("C4b_volume_test", 4), ("C5_part2_all", 2)])
+def test_full_resolution_properties(name, spp):
+    """BASELINE's full resolutions (spp reduced): size-independent properties instead of the oracle —
+    run-to-run determinism, ray accounting, finite output, and independence from the pool size."""
+    if name == "C4a_hdri_test":
+        s, r = scenes.hdri_test(scenes.synthetic_hdr(1024, 512))
+        r.width(1024).height(1024).samples(spp)
+    else:
+        s, r = scenes.config(name, samples=spp)
+    a = r.render_full(s)
+    b = r.paths_per_batch(r.settings["width"] * r.settings["height"] * max(1, spp // 2)).render_full(s)
+    assert np.array_equal(a.rgb8, b.rgb8) and np.array_equal(a.linear, b.linear, equal_nan=True)
+    st = a.stats
+    assert st["samples"] == r.settings["width"] * r.settings["height"] * spp
+    assert st["rays_per_depth"][0] == st["samples"] and st["rays"] == sum(st["rays_per_depth"])
+    assert all(x >= y for x, y in zip(st["rays_per_depth"], st["rays_per_depth"][1:]))
+    assert st["rays"] == b.stats["rays"]
+    assert np.isfinite(a.gamma[~np.isnan(a.gamma)]).all() and a.rgb8.any()
