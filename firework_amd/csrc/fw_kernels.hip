@@ -630,6 +630,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
                         int n_items = ((leafA >> 30) == NODE_DOUBLE) ? 2 : 1;
                         for (int qq = 0; qq < n_items; qq++) {
                             Obj o = load_obj_for_hit(sc.obj, items[qq]);
+                            if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)items[qq]], sc.obj_gate[2 * (size_t)items[qq] + 1], r.o, inv, TMIN, TMAX)) continue;
                             if (sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = items[qq]; continue; }   // park the first mesh
                             float t; uint32_t prim;
                             if (hit_object(sc, o, items[qq], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {

@@ -226,14 +226,14 @@ struct fw_scene {
     int device = 0;
     int n_cus = 256;
     fw::DScene d{};
-    DevBuf obj, tlas, blas, tri, tri_attr, tri_rank, obj_rank, mat, tex, images, hdr;
+    DevBuf obj, tlas, blas, tri, tri_attr, tri_rank, obj_rank, obj_gate, mat, tex, images, hdr;
     uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mat = 0, n_tex = 0;
     bool hdr_env = false;
     // workspace (grown on demand, reused across fw_render calls)
     DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, accum, wcount, totals, pixel_ids, out_rgb8, out_gamma, out_linear;
     std::vector<hipEvent_t> events;
     ~fw_scene() {
-        for (DevBuf *b : {&obj, &tlas, &blas, &tri, &tri_attr, &tri_rank, &obj_rank, &mat, &tex, &images, &hdr, &ray_a[0], &ray_a[1], &ray_b[0], &ray_b[1],
+        for (DevBuf *b : {&obj, &tlas, &blas, &tri, &tri_attr, &tri_rank, &obj_rank, &obj_gate, &mat, &tex, &images, &hdr, &ray_a[0], &ray_a[1], &ray_b[0], &ray_b[1],
                           &state[0], &state[1], &hits, &sample_rad, &accum, &wcount, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear})
             b->release();
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
@@ -286,6 +286,7 @@ struct Flattener {
         case FW_SHAPE_DISK:                                          // disk.rs:85-90 — degenerate box, kept as written
             sp.q3[0] = s.radius; sp.q3[2] = s.phi_max; sp.q3[3] = s.inner_radius;
             sp.box = {{-s.radius, 0.f, s.radius}, {-s.radius, 0.001f, s.radius}};
+            sp.flags |= fw::OF_GATE;
             return FW_OK;
         case FW_SHAPE_TRIANGLE_MESH: return mesh_params(s, sp);
         case FW_SHAPE_CONSTANT_MEDIUM: {                             // volume.rs:84-86: bbox of the inner shape
@@ -412,7 +413,25 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     try { bvh_build(tlas, world); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
     std::vector<uint32_t> obj_rank = reference_ranks(tlas, desc->n_objects);
     uint32_t ref_tlas_nodes = tlas.count();
-    if (use_sah()) { FlatBvh sah; sah_build(sah, world); tlas = std::move(sah); }
+    // gate boxes: the box of each object's leaf node in the reference tree (own box for a Leaf, the union for a
+    // DoubleLeaf).  In the reference an object is tested iff the ray hits that box (ancestors are supersets), which
+    // matters for shapes whose own box does not enclose them (OF_GATE): they stay exactly as (in)visible as there.
+    std::vector<float> gate((size_t)desc->n_objects * 8, 0.f);
+    std::vector<Box> build_boxes = world;
+    for (uint32_t i = 0; i < tlas.count(); i++) {
+        const float *nd = &tlas.nodes[(size_t)i * 8];
+        uint32_t A, B; std::memcpy(&A, nd + 3, 4); std::memcpy(&B, nd + 7, 4);
+        uint32_t kind = A >> 30;
+        if (kind == 0) continue;
+        uint32_t items[2] = {A & fw::NODE_MASK, B};
+        for (uint32_t q = 0; q < (kind == fw::NODE_DOUBLE ? 2u : 1u); q++) {
+            float *g = &gate[(size_t)items[q] * 8];
+            g[0] = nd[0]; g[1] = nd[1]; g[2] = nd[2]; g[4] = nd[4]; g[5] = nd[5]; g[6] = nd[6];
+            uint32_t kf; std::memcpy(&kf, &objs[(size_t)items[q] * fw::OBJ_Q * 4 + 3], 4);
+            if ((kf >> 8) & fw::OF_GATE) build_boxes[items[q]] = Box{{nd[0], nd[1], nd[2]}, {nd[4], nd[5], nd[6]}};
+        }
+    }
+    if (use_sah()) { FlatBvh sah; sah_build(sah, build_boxes); tlas = std::move(sah); }
 
     // materials / textures / images
     std::vector<float> mats((size_t)std::max(1u, desc->n_materials) * 8, 0.f), texs((size_t)std::max(1u, desc->n_textures) * 8, 0.f);
@@ -477,6 +496,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     up(sc->tri, fl.tri.data(), fl.tri.size() * 4);
     up(sc->tri_rank, fl.tri_rank.data(), fl.tri_rank.size() * 4);
     up(sc->obj_rank, obj_rank.data(), obj_rank.size() * 4);
+    up(sc->obj_gate, gate.data(), gate.size() * 4);
     if (fl.any_attr) up(sc->tri_attr, fl.tri_attr.data(), fl.tri_attr.size() * 4);
     up(sc->mat, mats.data(), mats.size() * 4);
     up(sc->tex, texs.data(), texs.size() * 4);
@@ -486,7 +506,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     fw::DScene &d = sc->d;
     d.obj = (const float4 *)sc->obj.p; d.tlas = (const float4 *)sc->tlas.p; d.blas = (const float4 *)sc->blas.p;
     d.tri = (const float4 *)sc->tri.p; d.tri_nrm = (const float4 *)sc->tri_attr.p;
-    d.tri_rank = (const uint32_t *)sc->tri_rank.p; d.obj_rank = (const uint32_t *)sc->obj_rank.p;
+    d.tri_rank = (const uint32_t *)sc->tri_rank.p; d.obj_rank = (const uint32_t *)sc->obj_rank.p; d.obj_gate = (const float4 *)sc->obj_gate.p;
     d.mat = (const float4 *)sc->mat.p; d.tex = (const float4 *)sc->tex.p; d.images = (const uint8_t *)sc->images.p;
     d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
     d.env.kind = e.kind;

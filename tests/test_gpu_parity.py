@@ -290,3 +290,61 @@ def test_full_resolution_properties(name, spp):
     assert all(x >= y for x, y in zip(st["rays_per_depth"], st["rays_per_depth"][1:]))
     assert st["rays"] == b.stats["rays"]
     assert np.isfinite(a.gamma[~np.isnan(a.gamma)]).all() and a.rgb8.any()
+
+
+def _random_scene(seed):
+    """Every shape / material / texture / environment kind, random transforms (incl. sub-2.56-degree rotations that
+    take the `cos_trace >= 0.999` branch of scene.rs:187,242), media around spheres and boxes, a small mesh."""
+    import math
+    from firework_amd.api import ColorEnv, Cone, Cylinder, Disk, IsotropicMat
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(rng.uniform(a, b))
+    sc = Scene.new()
+    img = (rng.random((8, 8, 3)) * 255).astype(np.uint8)
+    texs = [ConstantTexture.new((u(0.2, 0.9), u(0.2, 0.9), u(0.2, 0.9))), CheckerTexture.with_colors((0.1, 0.1, 0.1), (0.9, 0.9, 0.9), u(1, 6)),
+            PerlinNoiseTexture.new(u(0.5, 4)), TurbulenceTexture.new(3, u(0.5, 3)), MarbleTexture.new(3, u(0.5, 3)), ImageTexture.new(img)]
+    mats = [sc.add_material(LambertianMat.new(t)) for t in texs]
+    mats += [sc.add_material(MetalMat.new((u(0.5, 1), u(0.5, 1), u(0.5, 1)), u(0, 0.6))), sc.add_material(DielectricMat.new(u(1.2, 1.8))),
+             sc.add_material(EmissiveMat.with_color((u(2, 6), u(2, 6), u(2, 6))))]
+    pick = lambda: int(rng.choice(mats))
+
+    def rot():
+        k = rng.integers(0, 4)
+        if k == 0:
+            return Rotor3.identity()
+        if k == 1:
+            return Rotor3.from_rotation_xz(u(-0.03, 0.03))          # below the 0.999 threshold
+        if k == 2:
+            return Rotor3.from_rotation_xz(u(-3, 3))
+        return Rotor3.from_euler_angles(u(-1, 1), u(-1, 1), u(-1, 1))
+
+    makers = [lambda: Sphere.new(u(0.3, 1.0), pick()), lambda: Rect3d.with_size((u(0.4, 1.5), u(0.4, 1.5), u(0.4, 1.5)), pick()),
+              lambda: XYRect.new(-1, 1, -1, 1, u(-0.5, 0.5), pick()), lambda: XZRect.new(-1, 1, -1, 1, u(-0.5, 0.5), pick()),
+              lambda: YZRect.new(-1, 1, -1, 1, u(-0.5, 0.5), pick()), lambda: Cone.new(u(0.4, 1), u(0.5, 1.5), pick()),
+              lambda: Cylinder.partial(u(0.4, 1), u(0.5, 1.5), u(90, 360), pick()), lambda: Disk.partial(u(0.6, 1.2), u(90, 360), u(0, 0.4), pick())]
+    for _ in range(int(rng.integers(6, 14))):
+        ro = RenderObject.new(makers[int(rng.integers(0, len(makers)))]()).rotate(rot()).position(u(-4, 4), u(0, 3), u(-4, 4))
+        if rng.random() < 0.3:
+            ro = ro.flip_normals()
+        sc.add_object(ro)
+    # two media (sphere and box boundaries) and a little mesh with normals
+    sc.add_volume(RenderObject.new(Sphere.new(u(0.8, 1.5), mats[0])).position(u(-3, 3), 1.5, u(-3, 3)), u(0.3, 1.5), texs[0])
+    sc.add_volume(RenderObject.new(Rect3d.with_size((1.5, 1.5, 1.5), mats[0])).rotate(rot()).position(u(-3, 3), 0.2, u(-3, 3)), u(0.3, 1.5), texs[1])
+    n = 6
+    verts = np.array([[math.cos(2 * math.pi * k / n), math.sin(2 * math.pi * k / n), u(-0.2, 0.2)] for k in range(n)] + [[0, 0, 0.5]], np.float32)
+    idx = [v for k in range(n) for v in (n, k, (k + 1) % n)]
+    nrm = verts / np.maximum(np.linalg.norm(verts, axis=1, keepdims=True), 1e-3)
+    sc.add_object(RenderObject.new(TriangleMesh.new(verts, idx, nrm if seed % 2 else None, None, pick())).rotate(rot()).position(u(-2, 2), 1.5, u(-2, 2)))
+    # checker floor NOT on the plane y = 0: there CheckerTexture's sign(sin(scale*y)) is the sign of a rounding
+    # residue, i.e. noise in the reference itself, and any ulp upstream (log10f in a medium) flips the colour
+    sc.add_object(RenderObject.new(XZRect.new(-30.0, 30.0, -30.0, 30.0, -0.37, mats[1])))
+    sc.set_environment(SkyEnv.default() if seed % 3 else ColorEnv.new((0.3, 0.3, 0.4)))
+    cam = CameraSettings.default().cam_pos((u(-2, 2), u(2, 5), -11.0)).look_at((0.0, 1.0, 0.0)).field_of_view(40.0).aperture(u(0, 0.2)).focus_dist(11.0)
+    return sc, cam
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_scenes(oracle, seed):
+    sc, cam = _random_scene(seed)
+    r = Renderer.default().width(72).height(48).samples(8).use_bvh(bool(seed % 2)).camera(cam).seed(seed * 1000003)
+    check(oracle, sc, r, max_bad_pixels=12)      # ocml vs glibc ulps in sin/atan2/acos/log10/pow flip a few texels / Fresnel draws
