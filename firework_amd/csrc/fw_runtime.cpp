@@ -242,7 +242,8 @@ struct fw_scene {
 
 namespace {
 
-struct ShapeParams { float q3[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0}; uint32_t kind = 0, flags = 0, aux0 = 0, aux1 = 0; Box box{}; };
+struct ShapeParams { float q3[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0}; uint32_t kind = 0, flags = 0, aux0 = 0, aux1 = 0; Box box{};
+                     Box true_box{}; };   // OF_GATE shapes: a box that really encloses the geometry (object space)
 
 struct Flattener {
     const fw_scene_desc *d;
@@ -287,6 +288,7 @@ struct Flattener {
             sp.q3[0] = s.radius; sp.q3[2] = s.phi_max; sp.q3[3] = s.inner_radius;
             sp.box = {{-s.radius, 0.f, s.radius}, {-s.radius, 0.001f, s.radius}};
             sp.flags |= fw::OF_GATE;
+            sp.true_box = {{-s.radius, -0.001f, -s.radius}, {s.radius, 0.001f, s.radius}};
             return FW_OK;
         case FW_SHAPE_TRIANGLE_MESH: return mesh_params(s, sp);
         case FW_SHAPE_CONSTANT_MEDIUM: {                             // volume.rs:84-86: bbox of the inner shape
@@ -373,7 +375,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
 
     Flattener fl{desc};
     std::vector<float> objs((size_t)desc->n_objects * fw::OBJ_Q * 4, 0.f);
-    std::vector<Box> world(desc->n_objects);
+    std::vector<Box> world(desc->n_objects), true_world(desc->n_objects);
     bool has_medium = false;
     for (uint32_t i = 0; i < desc->n_objects; i++) {
         const fw_object &o = desc->objects[i];
@@ -384,19 +386,23 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         rotor_rows(o.rotation, rows);
         uint32_t flags = sp.flags;
         float cos_trace = 0.5f * ((rows[0][0] + rows[1][1] + rows[2][2]) - 1.f);     // scene.rs:180-185
-        Box rb = sp.box;
-        if (cos_trace < 0.999f) {
-            flags |= fw::OF_ROTATED;
-            V3 mn = 10e9f * V3{1, 1, 1}, mx = -10e9f * V3{1, 1, 1};                 // scene.rs:188-203
-            for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int c = 0; c < 2; c++) {
-                V3 corner{a == 0 ? sp.box.mn.x : sp.box.mx.x, b == 0 ? sp.box.mn.y : sp.box.mx.y, c == 0 ? sp.box.mn.z : sp.box.mx.z};
-                V3 np = mat_mul(rows, corner);
-                mx = {std::fmax(np.x, mx.x), std::fmax(np.y, mx.y), std::fmax(np.z, mx.z)};
-                mn = {std::fmin(np.x, mn.x), std::fmin(np.y, mn.y), std::fmin(np.z, mn.z)};
+        if (cos_trace < 0.999f) flags |= fw::OF_ROTATED;
+        auto to_world = [&](const Box &ob) {                                          // scene.rs:177-212
+            Box rb = ob;
+            if (cos_trace < 0.999f) {
+                V3 mn = 10e9f * V3{1, 1, 1}, mx = -10e9f * V3{1, 1, 1};               // scene.rs:188-203
+                for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) for (int c = 0; c < 2; c++) {
+                    V3 corner{a == 0 ? ob.mn.x : ob.mx.x, b == 0 ? ob.mn.y : ob.mx.y, c == 0 ? ob.mn.z : ob.mx.z};
+                    V3 np = mat_mul(rows, corner);
+                    mx = {std::fmax(np.x, mx.x), std::fmax(np.y, mx.y), std::fmax(np.z, mx.z)};
+                    mn = {std::fmin(np.x, mn.x), std::fmin(np.y, mn.y), std::fmin(np.z, mn.z)};
+                }
+                rb = {mn, mx};
             }
-            rb = {mn, mx};
-        }
-        world[i] = {rb.mn + tov(o.position), rb.mx + tov(o.position)};                // scene.rs:207-210
+            return Box{rb.mn + tov(o.position), rb.mx + tov(o.position)};             // scene.rs:207-210
+        };
+        world[i] = to_world(sp.box);
+        if (flags & fw::OF_GATE) true_world[i] = to_world(sp.true_box);
         if (o.flip_normals) flags |= fw::OF_FLIP;
         uint32_t kind = sp.kind & 0xffu, inner = (sp.kind >> 16) & 0xffu;
         if (kind == FW_SHAPE_CONSTANT_MEDIUM) has_medium = true;
@@ -428,7 +434,9 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
             float *g = &gate[(size_t)items[q] * 8];
             g[0] = nd[0]; g[1] = nd[1]; g[2] = nd[2]; g[4] = nd[4]; g[5] = nd[5]; g[6] = nd[6];
             uint32_t kf; std::memcpy(&kf, &objs[(size_t)items[q] * fw::OBJ_Q * 4 + 3], 4);
-            if ((kf >> 8) & fw::OF_GATE) build_boxes[items[q]] = Box{{nd[0], nd[1], nd[2]}, {nd[4], nd[5], nd[6]}};
+            // walked-tree box of a gated object: its gate box (so the gate test is reachable) united with bounds that
+            // really enclose the geometry (so culling against the best t so far stays valid)
+            if ((kf >> 8) & fw::OF_GATE) build_boxes[items[q]] = box_union(Box{{nd[0], nd[1], nd[2]}, {nd[4], nd[5], nd[6]}}, true_world[items[q]]);
         }
     }
     if (use_sah()) { FlatBvh sah; sah_build(sah, build_boxes); tlas = std::move(sah); }
