@@ -544,6 +544,7 @@ extern __shared__ uint32_t lds_stack[];
 // BLAS; it parks (slot, mesh object, best hit so far) in a wave-private LDS list, and whenever 64 entries have
 // accumulated the whole wave walks BLASes together, one parked ray per lane, and writes the final hit records.
 constexpr uint32_t DEFER_CAP = 128;   // entries; a chunk adds at most 64, a flush removes 64
+static_assert(FW_WB == 64, "the parked-ray list and the wave-private queues assume single-wave workgroups");
 
 template <bool USE_BVH>
 __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, float4 *__restrict__ hits,
