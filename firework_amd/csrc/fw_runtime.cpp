@@ -463,6 +463,18 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         default: return fail(FW_ERR_BAD_ARG, "unknown texture kind");
         }
     }
+    // CheckerTexture children must form a finite tree no deeper than the device's bounded walk (the reference would
+    // recurse forever on a cycle: texture.rs:59-72)
+    for (uint32_t i = 0; i < desc->n_textures; i++) {
+        std::vector<std::pair<int32_t, int>> todo{{(int32_t)i, 0}};
+        size_t visited = 0;
+        while (!todo.empty()) {
+            auto [ti, depth] = todo.back(); todo.pop_back();
+            if (depth > 14 || ++visited > 65536) return fail(FW_ERR_BAD_ARG, "CheckerTexture nesting too deep or cyclic");
+            const fw_texture &t = desc->textures[ti];
+            if (t.kind == FW_TEX_CHECKER) { todo.push_back({t.odd, depth + 1}); todo.push_back({t.even, depth + 1}); }
+        }
+    }
     for (uint32_t i = 0; i < desc->n_materials; i++) {
         const fw_material &m = desc->materials[i];
         float *q = &mats[(size_t)i * 8];
