@@ -49,6 +49,8 @@ def load():
     lib.fw_render_scene.restype = C.c_int
     lib.fw_render_scene.argtypes = [C.POINTER(A.fw_scene_desc), C.POINTER(A.fw_render_params), C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.POINTER(A.fw_stats)]
+    lib.fw_release_workspace.restype = None
+    lib.fw_release_workspace.argtypes = [C.c_int]
     lib.fw_selftest_arith.restype = C.c_int
     lib.fw_selftest_arith.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     if lib.fw_abi_version() != A.FW_ABI_VERSION:
@@ -67,6 +69,10 @@ def selftest_arith(n, seed=1, mode=0, device=0):
     d, s = C.c_uint64(), C.c_uint64()
     _check(lib, lib.fw_selftest_arith(device, n, seed, mode, C.byref(d), C.byref(s)))
     return int(d.value), int(s.value)
+
+
+def release_workspace(device=0):
+    load().fw_release_workspace(device)
 
 
 def device_count():

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -214,11 +215,52 @@ struct DevBuf {
     int upload(const void *src, size_t n) {
         int rc = alloc(n ? n : 16);
         if (rc) return rc;
-        if (n) HIPCHK(hipMemcpy(p, src, n, hipMemcpyHostToDevice));
+        if (n) {   // async copy + explicit wait: the blocking hipMemcpy of pageable memory showed 20-30 ms stalls
+            HIPCHK(hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, nullptr));
+            HIPCHK(hipStreamSynchronize(nullptr));
+        }
         return FW_OK;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
+
+
+// Per-device wavefront workspace: the path pools, accumulators and events.  It is the library's only global state
+// (created lazily, kept until fw_release_workspace or process exit): a one-shot `Renderer::render(scene)` would
+// otherwise hipMalloc/hipFree tens of GB per call, which costs from 8 ms to seconds (fresh pages are cleared).
+// Optionally (FIREWORK_STREAMS=n) up to MAX_LANES batches are in flight on their own streams, each with its own
+// path pool, so that one batch's k_extend (VALU-bound) overlaps another's k_shade (HBM-bound).  Results do not
+// depend on n (batches are accumulated in order).  Default 1: the measured gain is ~3 %.
+struct Workspace {
+    static constexpr int MAX_LANES = 4;
+    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, wcount; hipStream_t stream = nullptr; std::vector<hipEvent_t> events; };
+    std::mutex mu;                        // one fw_render at a time per device
+    Lane lanes[MAX_LANES];
+    DevBuf accum, totals, pixel_ids, out_rgb8, out_gamma, out_linear;
+    DevBuf scene_cache;                   // the last destroyed scene's allocation, reused by the next fw_scene_create
+    std::vector<hipEvent_t> events;       // [0] frame start, [1] frame stop, [2] fork, [3..] per-batch "accumulated" events
+    void release() {
+        for (DevBuf *b : {&accum, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear, &scene_cache}) b->release();
+        for (Lane &l : lanes) {
+            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount}) b->release();
+            for (hipEvent_t e : l.events) (void)hipEventDestroy(e);
+            l.events.clear();
+            if (l.stream) (void)hipStreamDestroy(l.stream);
+            l.stream = nullptr;
+        }
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        events.clear();
+    }
+};
+constexpr int MAX_DEVICES = 64;
+Workspace *workspace_for(int device) {
+    static Workspace *table[MAX_DEVICES] = {};
+    static std::mutex table_mu;
+    if (device < 0 || device >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> g(table_mu);
+    if (!table[device]) table[device] = new (std::nothrow) Workspace();   // intentionally never deleted (process lifetime)
+    return table[device];
+}
 
 } // namespace
 
@@ -226,28 +268,11 @@ struct fw_scene {
     int device = 0;
     int n_cus = 256;
     fw::DScene d{};
-    DevBuf obj, tlas, blas, tri, tri_attr, tri_rank, obj_rank, obj_gate, mat, tex, images, hdr;
+    DevBuf data;   // every scene array in one allocation (sections 256-byte aligned)
     uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mat = 0, n_tex = 0;
     bool hdr_env = false;
-    // workspace (grown on demand, reused across fw_render calls)
-    // Optionally (FIREWORK_STREAMS=n) up to MAX_LANES batches are in flight on their own streams, each with its own
-    // path pool, so that one batch's k_extend (VALU-bound) overlaps another's k_shade (HBM-bound).  Results do not
-    // depend on n (batches are accumulated in order).  Default 1: the measured gain is ~3 %.
-    static constexpr int MAX_LANES = 4;
-    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, wcount; hipStream_t stream = nullptr; std::vector<hipEvent_t> events; };
-    Lane lanes[MAX_LANES];
-    DevBuf accum, totals, pixel_ids, out_rgb8, out_gamma, out_linear;
-    std::vector<hipEvent_t> events;       // [0] frame start, [1] frame stop, [2] fork, [3..] per-batch "accumulated" events
     ~fw_scene() {
-        for (DevBuf *b : {&obj, &tlas, &blas, &tri, &tri_attr, &tri_rank, &obj_rank, &obj_gate, &mat, &tex, &images, &hdr,
-                          &accum, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear})
-            b->release();
-        for (Lane &l : lanes) {
-            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount}) b->release();
-            for (hipEvent_t e : l.events) (void)hipEventDestroy(e);
-            if (l.stream) (void)hipStreamDestroy(l.stream);
-        }
-        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+        data.release();
     }
 };
 
@@ -381,8 +406,14 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     if (desc->n_objects == 0 || !desc->objects) return fail(FW_ERR_EMPTY_SCENE, "No render objects added to scene!");
     if (desc->n_objects > fw::NODE_MASK) return fail(FW_ERR_UNSUPPORTED, "too many objects");
     HIPCHK(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, device));
+    // hipGetDeviceProperties costs up to ~25 ms per call: ask once per device
+    static int cu_cache[MAX_DEVICES] = {};
+    if (device < MAX_DEVICES && cu_cache[device] == 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        cu_cache[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int n_cus_dev = device < MAX_DEVICES ? cu_cache[device] : 256;
 
     Flattener fl{desc};
     std::vector<float> objs((size_t)desc->n_objects * fw::OBJ_Q * 4, 0.f);
@@ -518,33 +549,41 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     fw_scene *sc = new (std::nothrow) fw_scene();
     if (!sc) return fail(FW_ERR_OOM, "host allocation failed");
     sc->device = device;
-    sc->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    sc->n_cus = n_cus_dev;
     int rc = FW_OK;
-    auto up = [&](DevBuf &b, const void *p, size_t n) { if (!rc) rc = b.upload(p, n); };
-    up(sc->obj, objs.data(), objs.size() * 4);
-    up(sc->tlas, tlas.nodes.data(), tlas.nodes.size() * 4);
-    up(sc->blas, fl.blas.nodes.data(), fl.blas.nodes.size() * 4);
-    up(sc->tri, fl.tri.data(), fl.tri.size() * 4);
-    up(sc->tri_rank, fl.tri_rank.data(), fl.tri_rank.size() * 4);
-    up(sc->obj_rank, obj_rank.data(), obj_rank.size() * 4);
-    up(sc->obj_gate, gate.data(), gate.size() * 4);
-    if (fl.any_attr) up(sc->tri_attr, fl.tri_attr.data(), fl.tri_attr.size() * 4);
-    up(sc->mat, mats.data(), mats.size() * 4);
-    up(sc->tex, texs.data(), texs.size() * 4);
-    up(sc->images, images.data(), images.size());
-    if (e.kind == FW_ENV_HDR) up(sc->hdr, e.hdr_rgb, (size_t)e.hdr_w * e.hdr_h * 3 * 4);
+    // one device allocation + one copy for the whole scene (12 separate hipMalloc/hipFree pairs cost up to 30 ms of a
+    // one-shot render): sections are 256-byte aligned inside a host staging blob
+    struct Sec { const void *src; size_t bytes, off; };
+    Sec secs[12] = {
+        {objs.data(), objs.size() * 4, 0}, {tlas.nodes.data(), tlas.nodes.size() * 4, 0}, {fl.blas.nodes.data(), fl.blas.nodes.size() * 4, 0},
+        {fl.tri.data(), fl.tri.size() * 4, 0}, {fl.any_attr ? fl.tri_attr.data() : nullptr, fl.any_attr ? fl.tri_attr.size() * 4 : 0, 0},
+        {fl.tri_rank.data(), fl.tri_rank.size() * 4, 0}, {obj_rank.data(), obj_rank.size() * 4, 0}, {gate.data(), gate.size() * 4, 0},
+        {mats.data(), mats.size() * 4, 0}, {texs.data(), texs.size() * 4, 0}, {images.data(), images.size(), 0},
+        {e.kind == FW_ENV_HDR ? e.hdr_rgb : nullptr, e.kind == FW_ENV_HDR ? (size_t)e.hdr_w * e.hdr_h * 3 * 4 : 0, 0}};
+    size_t total = 0;
+    for (Sec &x : secs) { x.off = total; total += (x.bytes + 255) & ~(size_t)255; }
+    total = std::max<size_t>(total, 256);
+    std::vector<uint8_t> blob(total, 0);
+    for (const Sec &x : secs) if (x.bytes) std::memcpy(blob.data() + x.off, x.src, x.bytes);
+    if (Workspace *ws = workspace_for(device)) {     // reuse the previous scene's allocation when it is big enough
+        std::lock_guard<std::mutex> g(ws->mu);
+        if (ws->scene_cache.p && ws->scene_cache.bytes >= blob.size()) { sc->data = ws->scene_cache; ws->scene_cache = DevBuf{}; }
+    }
+    rc = sc->data.upload(blob.data(), blob.size());
     if (rc) { delete sc; return rc; }
+    const uint8_t *base = (const uint8_t *)sc->data.p;
     fw::DScene &d = sc->d;
-    d.obj = (const float4 *)sc->obj.p; d.tlas = (const float4 *)sc->tlas.p; d.blas = (const float4 *)sc->blas.p;
-    d.tri = (const float4 *)sc->tri.p; d.tri_nrm = (const float4 *)sc->tri_attr.p;
-    d.tri_rank = (const uint32_t *)sc->tri_rank.p; d.obj_rank = (const uint32_t *)sc->obj_rank.p; d.obj_gate = (const float4 *)sc->obj_gate.p;
-    d.mat = (const float4 *)sc->mat.p; d.tex = (const float4 *)sc->tex.p; d.images = (const uint8_t *)sc->images.p;
+    d.obj = (const float4 *)(base + secs[0].off); d.tlas = (const float4 *)(base + secs[1].off); d.blas = (const float4 *)(base + secs[2].off);
+    d.tri = (const float4 *)(base + secs[3].off); d.tri_nrm = (const float4 *)(base + secs[4].off);
+    d.tri_rank = (const uint32_t *)(base + secs[5].off); d.obj_rank = (const uint32_t *)(base + secs[6].off); d.obj_gate = (const float4 *)(base + secs[7].off);
+    d.mat = (const float4 *)(base + secs[8].off); d.tex = (const float4 *)(base + secs[9].off); d.images = base + secs[10].off;
+    const float *hdr_dev = (const float *)(base + secs[11].off);
     d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
     d.env.kind = e.kind;
     d.env.color[0] = e.color.x; d.env.color[1] = e.color.y; d.env.color[2] = e.color.z;
     d.env.zenith[0] = e.zenith.x; d.env.zenith[1] = e.zenith.y; d.env.zenith[2] = e.zenith.z;
     d.env.horizon[0] = e.horizon.x; d.env.horizon[1] = e.horizon.y; d.env.horizon[2] = e.horizon.z;
-    d.env.hdr = (const float *)sc->hdr.p; d.env.hdr_w = e.hdr_w; d.env.hdr_h = e.hdr_h;
+    d.env.hdr = hdr_dev; d.env.hdr_w = e.hdr_w; d.env.hdr_h = e.hdr_h;
     sc->hdr_env = e.kind == FW_ENV_HDR;
     sc->tlas_nodes = ref_tlas_nodes; sc->blas_nodes = fl.ref_blas_nodes;   // reported: the reference topology (bvh.rs)
     sc->tlas_depth = tlas.depth; sc->blas_depth = fl.blas_depth;
@@ -596,10 +635,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     if (p->pixel_ids) for (uint32_t i = 0; i < n_pix; i++) if (p->pixel_ids[i] >= full) return fail(FW_ERR_BAD_ARG, "pixel id out of range");
     HIPCHK(hipSetDevice(sc->device));
     hipStream_t stream = (hipStream_t)p->stream;
+    Workspace *ws = workspace_for(sc->device);
+    if (!ws) return fail(FW_ERR_OOM, "no workspace for this device");
+    std::lock_guard<std::mutex> ws_guard(ws->mu);
 
     // ---- batches and lanes -----------------------------------------------------------------------------------
     int n_lanes = 1;   // measured on cornell: 2-4 lanes overlap extend (VALU) with shade (HBM) for only ~3 % (63.4 -> 61.6 ms)
-    if (const char *e = getenv("FIREWORK_STREAMS")) { int v = atoi(e); if (v >= 1) n_lanes = std::min(v, (int)fw_scene::MAX_LANES); }
+    if (const char *e = getenv("FIREWORK_STREAMS")) { int v = atoi(e); if (v >= 1) n_lanes = std::min(v, (int)Workspace::MAX_LANES); }
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, p->samples);
     uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch() / (uint32_t)n_lanes;
     uint32_t spp_b = std::max<uint32_t>(1u, budget / n_pix);
@@ -627,28 +669,28 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     int rc = FW_OK;
     auto need = [&](DevBuf &b, size_t n) { if (!rc) rc = b.alloc(n); };
     for (int l = 0; l < n_lanes; l++) {
-        fw_scene::Lane &L = sc->lanes[l];
+        Workspace::Lane &L = ws->lanes[l];
         for (int k = 0; k < 2; k++) { need(L.ray_a[k], (size_t)cap * 16); need(L.ray_b[k], (size_t)cap * 8); need(L.state[k], (size_t)cap * 16); }
         need(L.hits, (size_t)cap * 16);
         need(L.sample_rad, (size_t)max_paths * 16);
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
         if (!rc && !L.stream && n_lanes > 1) HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     }
-    need(sc->accum, (size_t)n_pix * 16);
-    need(sc->totals, (size_t)n_batches * fw::COUNT_STRIDE * 4);
-    if (p->pixel_ids) need(sc->pixel_ids, (size_t)n_pix * 4);
+    need(ws->accum, (size_t)n_pix * 16);
+    need(ws->totals, (size_t)n_batches * fw::COUNT_STRIDE * 4);
+    if (p->pixel_ids) need(ws->pixel_ids, (size_t)n_pix * 4);
     uint8_t *d_rgb8 = rgb8; float *d_gamma = gamma_rgb, *d_linear = linear_rgb;
     if (!p->outputs_on_device) {
-        if (rgb8) { need(sc->out_rgb8, (size_t)n_pix * 3); d_rgb8 = (uint8_t *)sc->out_rgb8.p; }
-        if (gamma_rgb) { need(sc->out_gamma, (size_t)n_pix * 12); d_gamma = (float *)sc->out_gamma.p; }
-        if (linear_rgb) { need(sc->out_linear, (size_t)n_pix * 12); d_linear = (float *)sc->out_linear.p; }
+        if (rgb8) { need(ws->out_rgb8, (size_t)n_pix * 3); d_rgb8 = (uint8_t *)ws->out_rgb8.p; }
+        if (gamma_rgb) { need(ws->out_gamma, (size_t)n_pix * 12); d_gamma = (float *)ws->out_gamma.p; }
+        if (linear_rgb) { need(ws->out_linear, (size_t)n_pix * 12); d_linear = (float *)ws->out_linear.p; }
     }
     if (rc) return rc;
-    while (sc->events.size() < 3 + (size_t)n_batches) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, sc->events.size() < 2 ? hipEventDefault : hipEventDisableTiming)); sc->events.push_back(e); }
+    while (ws->events.size() < 3 + (size_t)n_batches) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, ws->events.size() < 2 ? hipEventDefault : hipEventDisableTiming)); ws->events.push_back(e); }
 
-    if (p->pixel_ids) HIPCHK(hipMemcpyAsync(sc->pixel_ids.p, p->pixel_ids, (size_t)n_pix * 4, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetAsync(sc->accum.p, 0, (size_t)n_pix * 16, stream));
-    HIPCHK(hipMemsetAsync(sc->totals.p, 0, (size_t)n_batches * fw::COUNT_STRIDE * 4, stream));
+    if (p->pixel_ids) HIPCHK(hipMemcpyAsync(ws->pixel_ids.p, p->pixel_ids, (size_t)n_pix * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetAsync(ws->accum.p, 0, (size_t)n_pix * 16, stream));
+    HIPCHK(hipMemsetAsync(ws->totals.p, 0, (size_t)n_batches * fw::COUNT_STRIDE * 4, stream));
 
     fw::LaunchCfg cfg;
     cfg.q = q;
@@ -662,7 +704,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
     fr.width = p->width; fr.height = p->height; fr.n_pixels = n_pix; fr.inv_n_pixels = 1.0f / (float)n_pix; fr.inv_width = 1.0f / (float)p->width;
-    fr.pixel_ids = p->pixel_ids ? (const uint32_t *)sc->pixel_ids.p : nullptr;
+    fr.pixel_ids = p->pixel_ids ? (const uint32_t *)ws->pixel_ids.p : nullptr;
     fr.seed32 = (uint32_t)p->seed ^ ((uint32_t)(p->seed >> 32) * 0x9E3779B9u);
 
     // per-launch timing (FW_FLAG_TIME_KERNELS): one event after every launch on the launch's own stream; the end of
@@ -673,19 +715,19 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     std::vector<size_t> ev_next(n_lanes, 0);
     if (timing) for (int l = 0; l < n_lanes; l++) {
         size_t want = 1 + per_batch_launches * ((n_batches + n_lanes - 1) / n_lanes);
-        auto &ev = sc->lanes[l].events;
+        auto &ev = ws->lanes[l].events;
         while (ev.size() < want) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ev.push_back(e); }
     }
     const bool use_bvh = p->use_bvh != 0;
 
-    HIPCHK(hipEventRecord(sc->events[0], stream));
+    HIPCHK(hipEventRecord(ws->events[0], stream));
     if (n_lanes > 1) {     // fork: the lane streams start after everything queued on the caller's stream so far
-        HIPCHK(hipEventRecord(sc->events[2], stream));
-        for (int l = 0; l < n_lanes; l++) HIPCHK(hipStreamWaitEvent(sc->lanes[l].stream, sc->events[2], 0));
+        HIPCHK(hipEventRecord(ws->events[2], stream));
+        for (int l = 0; l < n_lanes; l++) HIPCHK(hipStreamWaitEvent(ws->lanes[l].stream, ws->events[2], 0));
     }
     for (uint32_t b = 0; b < n_batches; b++) {
         const int l = (int)(b % (uint32_t)n_lanes);
-        fw_scene::Lane &L = sc->lanes[l];
+        Workspace::Lane &L = ws->lanes[l];
         hipStream_t ls = n_lanes > 1 ? L.stream : stream;
         cfg.stream = ls;
         cfg.q.wcount = (uint32_t *)L.wcount.p;
@@ -697,10 +739,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         fr.sample0 = b * spp_b;
         fr.spp_batch = std::min(spp_b, p->samples - fr.sample0);
         uint32_t n_paths = n_pix * fr.spp_batch;
-        uint32_t *totals = (uint32_t *)sc->totals.p + (size_t)b * fw::COUNT_STRIDE;
+        uint32_t *totals = (uint32_t *)ws->totals.p + (size_t)b * fw::COUNT_STRIDE;
         fw::DPaths buf[2];
         for (int k = 0; k < 2; k++) buf[k] = {(float4 *)L.ray_a[k].p, (float2 *)L.ray_b[k].p, (float4 *)L.state[k].p};
-        float4 *hits = (float4 *)L.hits.p, *srad = (float4 *)L.sample_rad.p, *accum = (float4 *)sc->accum.p;
+        float4 *hits = (float4 *)L.hits.p, *srad = (float4 *)L.sample_rad.p, *accum = (float4 *)ws->accum.p;
         int cur = 0;
         timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], n_paths); });
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
@@ -711,18 +753,18 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         timed(3, [&] { fw::launch_queue_totals(cfg, totals); });
         // `total_color += color(..)` in sample order (render.rs:181): batch b is accumulated after batch b-1, whichever
         // lanes they ran on, so the image does not depend on the number of lanes or batches
-        if (n_lanes > 1 && b > 0) HIPCHK(hipStreamWaitEvent(ls, sc->events[3 + b - 1], 0));
+        if (n_lanes > 1 && b > 0) HIPCHK(hipStreamWaitEvent(ls, ws->events[3 + b - 1], 0));
         timed(3, [&] { fw::launch_accumulate(cfg, fr, srad, accum); });
-        if (n_lanes > 1) HIPCHK(hipEventRecord(sc->events[3 + b], ls));
+        if (n_lanes > 1) HIPCHK(hipEventRecord(ws->events[3 + b], ls));
     }
-    if (n_lanes > 1) HIPCHK(hipStreamWaitEvent(stream, sc->events[3 + n_batches - 1], 0));    // join
+    if (n_lanes > 1) HIPCHK(hipStreamWaitEvent(stream, ws->events[3 + n_batches - 1], 0));    // join
     cfg.stream = stream;
-    fw::launch_resolve(cfg, fr, (const float4 *)sc->accum.p, p->samples, p->gamma, d_rgb8, d_gamma, d_linear);
-    HIPCHK(hipEventRecord(sc->events[1], stream));
+    fw::launch_resolve(cfg, fr, (const float4 *)ws->accum.p, p->samples, p->gamma, d_rgb8, d_gamma, d_linear);
+    HIPCHK(hipEventRecord(ws->events[1], stream));
     HIPCHK(hipGetLastError());
 
     std::vector<uint32_t> h_counts((size_t)n_batches * fw::COUNT_STRIDE);
-    HIPCHK(hipMemcpyAsync(h_counts.data(), sc->totals.p, h_counts.size() * 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_counts.data(), ws->totals.p, h_counts.size() * 4, hipMemcpyDeviceToHost, stream));
     if (!p->outputs_on_device) {
         if (rgb8) HIPCHK(hipMemcpyAsync(rgb8, d_rgb8, (size_t)n_pix * 3, hipMemcpyDeviceToHost, stream));
         if (gamma_rgb) HIPCHK(hipMemcpyAsync(gamma_rgb, d_gamma, (size_t)n_pix * 12, hipMemcpyDeviceToHost, stream));
@@ -737,14 +779,14 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             for (int s = 0; s < fw::MAX_SEGMENTS; s++) { uint64_t c = h_counts[(size_t)b * fw::COUNT_STRIDE + s]; stats->rays_per_depth[s] += c; stats->rays += c; }
         stats->algorithmic_bytes = 160 * stats->rays + 24 * stats->samples;   // SURVEY §8(d); HDR env misses are added by the caller that knows them
         float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, sc->events[0], sc->events[1]));
+        HIPCHK(hipEventElapsedTime(&ms, ws->events[0], ws->events[1]));
         stats->ms_render = ms;
         if (timing) {
             double acc[4] = {0, 0, 0, 0};
             for (int l = 0; l < n_lanes; l++)
                 for (size_t i = 0; i < ev_class[l].size(); i++) {
                     float t = 0.f;
-                    HIPCHK(hipEventElapsedTime(&t, sc->lanes[l].events[i], sc->lanes[l].events[i + 1]));
+                    HIPCHK(hipEventElapsedTime(&t, ws->lanes[l].events[i], ws->lanes[l].events[i + 1]));
                     acc[ev_class[l][i]] += t;
                 }
             stats->ms_raygen = acc[0]; stats->ms_extend = acc[1]; stats->ms_shade = acc[2]; stats->ms_accumulate = acc[3];
@@ -810,9 +852,20 @@ int fw_scene_create(const fw_scene_desc *desc, int device, fw_scene **out) {
     catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_scene_create"); }
 }
 
+void fw_release_workspace(int device) {
+    Workspace *ws = workspace_for(device);
+    if (!ws) return;
+    std::lock_guard<std::mutex> g(ws->mu);
+    if (hipSetDevice(device) == hipSuccess) ws->release();
+}
+
 void fw_scene_destroy(fw_scene *scene) {
     if (!scene) return;
     (void)hipSetDevice(scene->device);
+    if (Workspace *ws = workspace_for(scene->device)) {   // keep the allocation for the next scene (one-shot renders)
+        std::lock_guard<std::mutex> g(ws->mu);
+        if (scene->data.p && scene->data.bytes > ws->scene_cache.bytes) { ws->scene_cache.release(); ws->scene_cache = scene->data; scene->data = DevBuf{}; }
+    }
     delete scene;
 }
 

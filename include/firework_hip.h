@@ -245,6 +245,10 @@ int fw_render(fw_scene *scene, const fw_render_params *params,
 int fw_render_scene(const fw_scene_desc *desc, const fw_render_params *params, int device,
                     uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats);
 
+/* The wavefront workspace (path pools, tens of GB for big frames) is cached per device between calls — the library's
+   only global state.  This frees it (e.g. before handing the GPU to another library). */
+void fw_release_workspace(int device);
+
 /* Diagnostic: the kernels' division / square-root helpers against the compiler's IEEE expansion, bit for bit,
    on n hashed operand pairs.  mode 0 = magnitudes 2^-40..2^40 (must be 0 mismatches), mode 1 = all bit patterns. */
 int fw_selftest_arith(int device, uint32_t n, uint32_t seed, int mode, uint64_t *div_mismatches, uint64_t *sqrt_mismatches);
