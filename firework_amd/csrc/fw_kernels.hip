@@ -414,19 +414,16 @@ __device__ __forceinline__ bool hit_triangle(V3 p0, V3 p1, V3 p2, const Ray &r, 
     return true;
 }
 
-// aabb.rs:30-50 with the reciprocal directions hoisted (1/d is the same value every call)
+// aabb.rs:30-50 with the reciprocal directions hoisted (1/d is the same value every call) and ONE comparison: the
+// reference leaves its per-axis `all()` at the first axis with tmax <= tmin, but tmin only grows and tmax only shrinks
+// (f32::max/min ignore NaN, so neither ever becomes NaN), hence a failed axis implies the final tmax <= tmin as well.
 __device__ __forceinline__ bool hit_aabb(float4 lo, float4 hi, V3 o, V3 inv, float tmin, float tmax) {
     float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
-    if (inv.x < 0.f) { float s = t0; t0 = t1; t1 = s; }
-    tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1);
-    if (!(tmax > tmin)) return false;
+    tmin = fmaxf(tmin, inv.x < 0.f ? t1 : t0); tmax = fminf(tmax, inv.x < 0.f ? t0 : t1);
     t0 = (lo.y - o.y) * inv.y; t1 = (hi.y - o.y) * inv.y;
-    if (inv.y < 0.f) { float s = t0; t0 = t1; t1 = s; }
-    tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1);
-    if (!(tmax > tmin)) return false;
+    tmin = fmaxf(tmin, inv.y < 0.f ? t1 : t0); tmax = fminf(tmax, inv.y < 0.f ? t0 : t1);
     t0 = (lo.z - o.z) * inv.z; t1 = (hi.z - o.z) * inv.z;
-    if (inv.z < 0.f) { float s = t0; t0 = t1; t1 = s; }
-    tmin = fmaxf(tmin, t0); tmax = fminf(tmax, t1);
+    tmin = fmaxf(tmin, inv.z < 0.f ? t1 : t0); tmax = fminf(tmax, inv.z < 0.f ? t0 : t1);
     return tmax > tmin;
 }
 
