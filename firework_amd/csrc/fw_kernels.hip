@@ -382,29 +382,38 @@ __device__ __forceinline__ int max_component_idx(V3 v) {
     return (v.z > v.y) ? 2 : 1;
 }
 
-// objects/mesh.rs:139-219.  Returns t and the barycentrics.
-__device__ __forceinline__ bool hit_triangle(V3 p0, V3 p1, V3 p2, const Ray &r, float tmin, float tmax,
-                                             float &t_out, float &b0, float &b1, float &b2) {
-    V3 p0t = p0 - r.o, p1t = p1 - r.o, p2t = p2 - r.o;
-    int kz = max_component_idx(r.d);
-    int kx = (kz + 1) % 3;
-    int ky = (kx + 1) % 3;
-    V3 d = mk(comp(r.d, kx), comp(r.d, ky), comp(r.d, kz));
-    p0t = mk(comp(p0t, kx), comp(p0t, ky), comp(p0t, kz));
-    p1t = mk(comp(p1t, kx), comp(p1t, ky), comp(p1t, kz));
-    p2t = mk(comp(p2t, kx), comp(p2t, ky), comp(p2t, kz));
+// objects/mesh.rs:139-219.  The permutation (kx,ky,kz) and the shear (sx,sy,sz) depend on the ray only
+// (mesh.rs:147-162), so a BLAS walk computes them once (TriRay) instead of once per triangle: three divisions and the
+// signed max-component search leave the per-triangle path.  Returns t and the barycentrics.
+struct TriRay { V3 o; int kx, ky, kz; float sx, sy, sz; };
+__device__ __forceinline__ TriRay make_triray(const Ray &r) {
+    TriRay q;
+    q.o = r.o;
+    q.kz = max_component_idx(r.d);
+    q.kx = (q.kz + 1) % 3;
+    q.ky = (q.kx + 1) % 3;
+    V3 d = mk(comp(r.d, q.kx), comp(r.d, q.ky), comp(r.d, q.kz));
     Rcp dz = make_rcp(d.z);
-    float sx = fdiv(-d.x, dz), sy = fdiv(-d.y, dz), sz = fdiv(1.f, dz);
-    p0t.x += sx * p0t.z; p0t.y += sy * p0t.z;
-    p1t.x += sx * p1t.z; p1t.y += sy * p1t.z;
-    p2t.x += sx * p2t.z; p2t.y += sy * p2t.z;
+    q.sx = fdiv(-d.x, dz); q.sy = fdiv(-d.y, dz); q.sz = fdiv(1.f, dz);
+    return q;
+}
+__device__ __forceinline__ bool hit_triangle(V3 p0, V3 p1, V3 p2, const TriRay &q, float tmin, float tmax,
+                                             float &t_out, float &b0, float &b1, float &b2) {
+    V3 p0t = p0 - q.o, p1t = p1 - q.o, p2t = p2 - q.o;
+    p0t = mk(comp(p0t, q.kx), comp(p0t, q.ky), comp(p0t, q.kz));
+    p1t = mk(comp(p1t, q.kx), comp(p1t, q.ky), comp(p1t, q.kz));
+    p2t = mk(comp(p2t, q.kx), comp(p2t, q.ky), comp(p2t, q.kz));
+    p0t.x += q.sx * p0t.z; p0t.y += q.sy * p0t.z;
+    p1t.x += q.sx * p1t.z; p1t.y += q.sy * p1t.z;
+    p2t.x += q.sx * p2t.z; p2t.y += q.sy * p2t.z;
     float e0 = p1t.x * p2t.y - p1t.y * p2t.x;
     float e1 = p2t.x * p0t.y - p2t.y * p0t.x;
     float e2 = p0t.x * p1t.y - p0t.y * p1t.x;
-    if ((e0 < 0.f || e1 < 0.f || e2 < 0.f) && (e0 > 0.f || e1 > 0.f || e2 > 0.f)) return false;
+    // (e0<0 || e1<0 || e2<0) && (e0>0 || e1>0 || e2>0), as two comparisons (fminf/fmaxf drop NaNs like the ORs do)
+    if (fminf(fminf(e0, e1), e2) < 0.f && fmaxf(fmaxf(e0, e1), e2) > 0.f) return false;
     float det = e0 + e1 + e2;
     if (det == 0.f) return false;
-    p0t.z *= sz; p1t.z *= sz; p2t.z *= sz;
+    p0t.z *= q.sz; p1t.z *= q.sz; p2t.z *= q.sz;
     float t_scaled = e0 * p0t.z + e1 * p1t.z + e2 * p2t.z;
     if (det < 0.f && (t_scaled >= tmin * det || t_scaled < tmax * det)) return false;
     else if (det > 0.f && (t_scaled <= tmin * det || t_scaled > tmax * det)) return false;
@@ -445,6 +454,8 @@ struct LdsStack {
 __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32_t tri_base, const Ray &r, float tmin,
                                          float tmax, float cull_t, uint32_t *stack_base, float &t_out, uint32_t &tri_out) {
     V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+    const TriRay tr = make_triray(r);
+    const uint32_t dir_neg = (r.d.x >= 0.f ? 0u : 1u) | (r.d.y >= 0.f ? 0u : 2u) | (r.d.z >= 0.f ? 0u : 4u);   // !(d >= 0): NaN counts as negative
     LdsStack st{stack_base, 0};
     bool have = false; float best = tmax; uint32_t best_tri = 0;
     const uint32_t DONE = 0xffffffffu;
@@ -459,7 +470,7 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
             bool hit = hit_aabb(lo, hi, r.o, inv, tmin, have ? fminf(best, cull_t) : cull_t);
             uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
             if (hit && (A >> 30) == 0u) {
-                bool left_first = comp(r.d, (int)(B & 3u)) >= 0.f;
+                bool left_first = ((dir_neg >> (B & 3u)) & 1u) == 0u;
                 uint32_t left = node + 1, right = A & NODE_MASK;
                 st.push(left_first ? right : left);
                 node = left_first ? left : right;
@@ -475,7 +486,7 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
                 const float4 *tp = sc.tri + 3 * (size_t)(tri_base + items[q]);
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, b0, b1, b2;
-                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), r, tmin, tmax, t, b0, b1, b2)) {
+                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, tmin, tmax, t, b0, b1, b2)) {
                     // tie -> the item that comes later in the reference tree's in-order (ranks fetched only then)
                     if (!have || t < best || (t == best && sc.tri_rank[tri_base + items[q]] > sc.tri_rank[tri_base + best_tri])) { have = true; best = t; best_tri = items[q]; }
                 }
@@ -601,6 +612,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
             } else {
                 // bvh.rs:88-98,115-151 over RenderObjectInternal items; same front-to-back scheme as hit_mesh
                 V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                const uint32_t dir_neg = (r.d.x >= 0.f ? 0u : 1u) | (r.d.y >= 0.f ? 0u : 2u) | (r.d.z >= 0.f ? 0u : 4u);
                 LdsStack st{my_stack, 0};
                 bool have = false;
                 const uint32_t DONE = 0xffffffffu;
@@ -614,7 +626,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
                         bool hitb = hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX);
                         uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
                         if (hitb && (A >> 30) == 0u) {
-                            bool left_first = comp(r.d, (int)(B & 3u)) >= 0.f;
+                            bool left_first = ((dir_neg >> (B & 3u)) & 1u) == 0u;
                             uint32_t left = node + 1, right = A & NODE_MASK;
                             st.push(left_first ? right : left);
                             node = left_first ? left : right;
@@ -814,7 +826,7 @@ __device__ __forceinline__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, c
         float4 a = tp[0], b = tp[1], c = tp[2];
         V3 p0 = mk(a.x, a.y, a.z), p1 = mk(b.x, b.y, b.z), p2 = mk(c.x, c.y, c.z);
         float tt, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-        hit_triangle(p0, p1, p2, r, -3.40282347e+38f, 3.40282347e+38f, tt, b0, b1, b2);   // same e0..e2/det as in k_extend
+        hit_triangle(p0, p1, p2, make_triray(r), -3.40282347e+38f, 3.40282347e+38f, tt, b0, b1, b2);   // same e0..e2/det as in k_extend
         p = b0 * p0 + b1 * p1 + b2 * p2;
         h.u = b0 * a.w + b1 * b.w + b2 * c.w;
         if (flags & OF_MESH_ATTR) {
