@@ -126,13 +126,13 @@ def main():
         if not args.no_kernel_timing:
             # rank-0 kernel classes (every rank runs the same kernels on 1/N of the pixels).
             # Algorithmic HBM bytes of THIS implementation's layout, exact from the counters:
-            #   k_extend: reads ray 24 B, writes hit 16 B                         -> 40 B per ray
-            #   k_shade : reads ray 24 + hit 16 + state 16; writes ray 24 + state 16 per continuing path,
-            #             radiance 16 per terminated path                        -> 96*rays - 24*samples
+            #   k_extend: reads ray 24 B, writes hit 8 B                          -> 32 B per ray
+            #   k_shade : reads ray 24 + hit 8 + state 16; writes ray 24 + state 16 per continuing path,
+            #             radiance 16 per terminated path                        -> 88*rays - 24*samples
             # (SURVEY §8d's generic figure is 40 + 120 = 160 B/ray; this layout moves fewer bytes.)
             rays0, samples0 = acc["rays"], acc["samples"]
-            ext_bytes = 40.0 * rays0
-            shd_bytes = 96.0 * rays0 - 24.0 * samples0
+            ext_bytes = 32.0 * rays0
+            shd_bytes = 88.0 * rays0 - 24.0 * samples0
             ext_s, shd_s = acc["ms_extend"] / 1e3, acc["ms_shade"] / 1e3
             dom = "k_extend" if ext_s >= shd_s else "k_shade"
             b, t = (ext_bytes, ext_s) if dom == "k_extend" else (shd_bytes, shd_s)

@@ -76,6 +76,7 @@ struct DScene {
     uint32_t n_objects;
     uint32_t has_medium;
     uint32_t has_mesh;
+    uint32_t prim_bits;       // hit code = object << prim_bits | primitive
     DEnv env;
 };
 
@@ -127,8 +128,8 @@ struct LaunchCfg {
 constexpr size_t LDS_TABLE_LIMIT = 16 * 1024;   // object+material+texture tables up to this size are staged in LDS
 
 void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, uint32_t n_paths);
-void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float4 *hits, int segment, bool use_bvh);
-void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, const float4 *hits,
+void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float2 *hits, int segment, bool use_bvh);
+void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment);
 void launch_queue_totals(const LaunchCfg &, uint32_t *totals);
 void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out);

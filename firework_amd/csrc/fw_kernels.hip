@@ -159,6 +159,12 @@ __device__ __forceinline__ RngKey key_of(const DFrame &f, uint32_t path_id) {
 constexpr int WB = FW_WB;
 __device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (WB / 64) + (threadIdx.x >> 6); }
 
+// Hit record: 8 bytes (t, code) with code = object << prim_bits | primitive (rect3d face / mesh triangle), MISS = all
+// ones.  k_shade is HBM-bound (88 % of what its streams can reach), so bytes are what it pays for.
+__device__ __forceinline__ float2 pack_hit(float t, uint32_t obj, uint32_t prim, uint32_t prim_bits) {
+    return make_float2(t, __uint_as_float(obj == MISS ? MISS : ((obj << prim_bits) | prim)));
+}
+
 // Wave w generates the paths  id = chunk * (n_waves*64) + w*64 + lane  (chunks of 64 consecutive pixels of
 // one sample index, dealt round-robin to the waves: coherent inside a wave, balanced across waves).
 __global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out, DQueue q, uint32_t n_paths) {
@@ -555,7 +561,7 @@ constexpr uint32_t DEFER_CAP = 128;   // entries; a chunk adds at most 64, a flu
 static_assert(FW_WB == 64, "the parked-ray list and the wave-private queues assume single-wave workgroups");
 
 template <bool USE_BVH>
-__global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, float4 *__restrict__ hits,
+__global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits,
                                                   DQueue q, int segment, int tlas_levels, int stack_levels) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     if (w >= q.n_waves) return;
@@ -583,7 +589,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
             if (hit_mesh(sc, o.aux0, o.aux1, r, TMIN, TMAX, bt, blas_stack, t, prim)) {
                 if (bobj == MISS || t < bt || (t == bt && sc.obj_rank[obj] > sc.obj_rank[bobj])) { bt = t; bobj = obj; bprim = prim; }
             }
-            hits[slot] = make_float4(bt, __uint_as_float(bobj), __uint_as_float(bprim), 0.f);
+            hits[slot] = pack_hit(bt, bobj, bprim, sc.prim_bits);
         }
     };
 
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
                     }
                 }
             }
-            if (!deferred) hits[i] = make_float4(best_t, __uint_as_float(best_obj), __uint_as_float(best_prim), 0.f);
+            if (!deferred) hits[i] = pack_hit(best_t, best_obj, best_prim, sc.prim_bits);
         }
         if (USE_BVH && sc.has_mesh) {
             unsigned long long mask = __ballot(deferred);
@@ -890,7 +896,7 @@ __device__ __forceinline__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, c
 extern __shared__ float4 lds_tables[];
 
 template <bool LDS_TAB>
-__global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DPaths out, const float4 *__restrict__ hits,
+__global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DPaths out, const float2 *__restrict__ hits,
                                                  float4 *__restrict__ sample_rad, DQueue q, int segment,
                                                  uint32_t n_mat, uint32_t n_tex) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
@@ -908,12 +914,12 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     const uint32_t base = w * q.cap;
     uint32_t out_n = 0;                                                  // survivors written so far (wave-uniform)
     // software pipeline: next chunk's ray / state / hit are in flight while the current chunk is shaded
-    float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n, hr_n = ra_n; float2 rb_n = make_float2(0, 0);
+    float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n; float2 rb_n = make_float2(0, 0), hr_n = rb_n;
     if (lane < n) { ra_n = in.ray_a[base + lane]; rb_n = in.ray_b[base + lane]; st_n = in.state[base + lane]; hr_n = hits[base + lane]; }
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
         const uint32_t j = c0 + lane;
         const uint32_t i = base + j;
-        float4 ra = ra_n, st = st_n, hr = hr_n; float2 rb = rb_n;
+        float4 ra = ra_n, st = st_n; float2 rb = rb_n, hr = hr_n;
         if (j + 64u < n) { ra_n = in.ray_a[i + 64u]; rb_n = in.ray_b[i + 64u]; st_n = in.state[i + 64u]; hr_n = hits[i + 64u]; }
         bool alive = false;
         Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
@@ -921,7 +927,8 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
             Ray r{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
             V3 beta = mk(st.x, st.y, st.z);
             path_id = __float_as_uint(st.w);
-            uint32_t obj_index = __float_as_uint(hr.y);
+            const uint32_t hit_code = __float_as_uint(hr.y);
+            const uint32_t obj_index = hit_code == MISS ? MISS : (hit_code >> sc.prim_bits);
             V3 rad = mk(0.f, 0.f, 0.f);
             if (obj_index == MISS) {
                 // render.rs:31; ColorEnv ignores the direction, so its normalisation (sqrt + 3 divisions) is skipped
@@ -932,7 +939,7 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
                 float4 m0 = matp[2 * o.material], m1 = matp[2 * o.material + 1];
                 uint32_t mbits = __float_as_uint(m0.x), mkind = mbits & 0xffu, mtex = __float_as_uint(m0.y);
                 bool need_uv = (mbits & MF_NEEDS_UV) != 0, tex_const = (mbits & MF_TEX_CONST) != 0;
-                HitInfo h = rebuild_hit(sc, o, r, hr.x, __float_as_uint(hr.z), need_uv);
+                HitInfo h = rebuild_hit(sc, o, r, hr.x, hit_code & ((1u << sc.prim_bits) - 1u), need_uv);
                 V3 texc = mk(m1.x, m1.y, m1.z);                                      // inline ConstantTexture / Metal albedo
                 if (!tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
                 if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
@@ -1069,7 +1076,7 @@ static dim3 wave_grid(const LaunchCfg &c) { return dim3((c.q.n_waves + WB / 64 -
 void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPaths out, uint32_t n_paths) {
     hipLaunchKernelGGL(k_raygen, wave_grid(c), dim3(WB), 0, c.stream, cam, f, out, c.q, n_paths);
 }
-void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float4 *hits, int segment, bool use_bvh) {
+void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float2 *hits, int segment, bool use_bvh) {
     int tl = use_bvh ? c.tlas_depth + 1 : 0;
     int levels = tl + c.blas_depth + 1;
     size_t lds = (size_t)levels * WB * sizeof(uint32_t) + (use_bvh && c.has_mesh ? 5 * DEFER_CAP * sizeof(uint32_t) : 0);
@@ -1077,7 +1084,7 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     if (use_bvh) hipLaunchKernelGGL(k_extend<true>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else hipLaunchKernelGGL(k_extend<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
-void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float4 *hits,
+void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment) {
     size_t tab = ((size_t)sc.n_objects * OBJ_Q + 2 * (size_t)c.n_mat + 2 * (size_t)c.n_tex) * sizeof(float4);
     if (c.lds_tables && tab <= LDS_TABLE_LIMIT)

@@ -287,7 +287,7 @@ struct Flattener {
     std::vector<uint32_t> tri_rank;       // in-order rank of each triangle in the reference tree of its mesh
     bool any_attr = false;
     FlatBvh blas;
-    uint32_t blas_depth = 0, ref_blas_nodes = 0;
+    uint32_t blas_depth = 0, ref_blas_nodes = 0, max_tris = 0;
 
     int check_material(int32_t m) const { return (m < 0 || (uint32_t)m >= d->n_materials) ? FW_ERR_BAD_ARG : FW_OK; }
 
@@ -347,6 +347,7 @@ struct Flattener {
         if (!s.verts || !s.indices || s.n_indices % 3) return fail(FW_ERR_BAD_ARG, "TriangleMesh needs verts and 3*k indices");
         if (s.n_indices == 0) return fail(FW_ERR_EMPTY_SCENE, "TriangleMesh with no triangles (reference: unbounded recursion in bvh.rs:29-70)");
         uint32_t n_tris = s.n_indices / 3, tri_base = (uint32_t)(tri.size() / 12);
+        max_tris = std::max(max_tris, n_tris);
         if ((uint64_t)tri_base + n_tris > fw::NODE_MASK) return fail(FW_ERR_UNSUPPORTED, "too many triangles");
         bool attr = s.normals || s.uvs;
         std::vector<Box> boxes(n_tris);
@@ -456,6 +457,13 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         std::memcpy(q + 8, sp.q4, 16);
         const uint32_t tail[3] = {(uint32_t)material, sp.aux0, sp.aux1};
         for (int r = 0; r < 3; r++) { q[12 + 4 * r] = rows[r][0]; q[13 + 4 * r] = rows[r][1]; q[14 + 4 * r] = rows[r][2]; q[15 + 4 * r] = bits_f(tail[r]); }
+    }
+    // packed hit records: object << prim_bits | primitive must fit 32 bits with all-ones left for MISS
+    uint32_t prim_bits = 3;                                   // rect3d faces 0..5
+    while (prim_bits < 31 && (1ull << prim_bits) < (uint64_t)fl.max_tris) prim_bits++;
+    {
+        uint32_t obj_bits = 1; while (obj_bits < 32 && (1ull << obj_bits) < (uint64_t)desc->n_objects + 1) obj_bits++;
+        if (obj_bits + prim_bits > 32) return fail(FW_ERR_UNSUPPORTED, "objects x triangles-per-mesh exceed the 32-bit hit code");
     }
     FlatBvh tlas;
     try { bvh_build(tlas, world); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
@@ -579,6 +587,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.mat = (const float4 *)(base + secs[8].off); d.tex = (const float4 *)(base + secs[9].off); d.images = base + secs[10].off;
     const float *hdr_dev = (const float *)(base + secs[11].off);
     d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
+    d.prim_bits = prim_bits;
     d.env.kind = e.kind;
     d.env.color[0] = e.color.x; d.env.color[1] = e.color.y; d.env.color[2] = e.color.z;
     d.env.zenith[0] = e.zenith.x; d.env.zenith[1] = e.zenith.y; d.env.zenith[2] = e.zenith.z;
@@ -614,12 +623,12 @@ fw::DCamera make_camera(const fw_camera_settings &s, uint32_t width, uint32_t he
 
 // Wavefront pool size.  Bigger is better on this part: fewer, fuller launches and longer wave-private queues
 // (measured on cornell 512x512@1024: 4 Mi paths 85 ms/frame, 16 Mi 64 ms, 256 Mi = the whole frame 55 ms).
-// Default: up to 2^28 path slots (112 B each = 30 GB), never more than half of the free HBM.
+// Default: up to 2^28 path slots (104 B each = 28 GB), never more than half of the free HBM.
 uint32_t default_paths_per_batch() {
     if (const char *e = getenv("FIREWORK_PATHS_PER_BATCH")) { long long v = atoll(e); if (v > 0) return (uint32_t)std::min<long long>(v, 0x7fffffffll); }
     size_t free_b = 0, total_b = 0;
     uint64_t budget = 1ull << 28;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, (uint64_t)(free_b / 2) / 112u);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, (uint64_t)(free_b / 2) / 104u);
     return (uint32_t)std::max<uint64_t>(budget, 1u << 16);
 }
 
@@ -671,7 +680,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     for (int l = 0; l < n_lanes; l++) {
         Workspace::Lane &L = ws->lanes[l];
         for (int k = 0; k < 2; k++) { need(L.ray_a[k], (size_t)cap * 16); need(L.ray_b[k], (size_t)cap * 8); need(L.state[k], (size_t)cap * 16); }
-        need(L.hits, (size_t)cap * 16);
+        need(L.hits, (size_t)cap * 8);
         need(L.sample_rad, (size_t)max_paths * 16);
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
         if (!rc && !L.stream && n_lanes > 1) HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
@@ -742,7 +751,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         uint32_t *totals = (uint32_t *)ws->totals.p + (size_t)b * fw::COUNT_STRIDE;
         fw::DPaths buf[2];
         for (int k = 0; k < 2; k++) buf[k] = {(float4 *)L.ray_a[k].p, (float2 *)L.ray_b[k].p, (float4 *)L.state[k].p};
-        float4 *hits = (float4 *)L.hits.p, *srad = (float4 *)L.sample_rad.p, *accum = (float4 *)ws->accum.p;
+        float2 *hits = (float2 *)L.hits.p;
+        float4 *srad = (float4 *)L.sample_rad.p, *accum = (float4 *)ws->accum.p;
         int cur = 0;
         timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], n_paths); });
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
