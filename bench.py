@@ -117,7 +117,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config} {s['width']}x{s['height']} @{s['samples']}spp", "use_bvh": bool(s["use_bvh"]),
-                       "tiles": "32x32 round-robin over ranks", "collective": f"one gather of u8 tiles to rank 0 ({args.backend})" if world > 1 else "none",
+                       "tiles": "16x16, dealt diagonally over ranks", "collective": f"one gather of u8 tiles to rank 0 ({args.backend})" if world > 1 else "none",
                        "rng": "counter (pcg4d) keyed by (seed,pixel,sample,dimension)", "seed": s["seed"]},
             "msamples_per_s": total_samples / elapsed / 1e6,
             "frame_time_ms": ms_step,

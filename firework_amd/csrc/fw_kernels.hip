@@ -299,7 +299,9 @@ __device__ __forceinline__ bool hit_rect_kind(uint32_t kind, float4 q3, float k,
     return hit_rect<2>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
 }
 
-// objects/rect3d.rs:18-100 — faces +z, -z, +y, -y, +x, -x; linear closest with narrowing, later wins ties
+// objects/rect3d.rs:18-100 — faces +z, -z, +y, -y, +x, -x; linear closest with narrowing, later wins ties.
+// (Measured and rejected: the two parallel faces of an axis as one packed-f32 computation — v_pk_fma/mul/add issue at half
+// the rate of their scalar forms on gfx950, tools/microbench.hip, so nothing is gained and the repacking costs: 28.0 vs 24.3 ms.)
 __device__ __forceinline__ bool hit_rect3d(float4 q3, float4 q4, const Ray &r, float tmin, float tmax, float &t_out, uint32_t &face) {
     float px = q3.x, py = q3.y, pz = q3.z, sx = q3.w, sy = q4.x, sz = q4.y;
     bool any = false; float closest = tmax, t; face = 0;
@@ -560,6 +562,63 @@ extern __shared__ uint32_t lds_stack[];
 constexpr uint32_t DEFER_CAP = 128;   // entries; a chunk adds at most 64, a flush removes 64
 static_assert(FW_WB == 64, "the parked-ray list and the wave-private queues assume single-wave workgroups");
 
+// Closest hit of one ray: the linear scan of scene.rs:137-149 or the TLAS walk of bvh.rs:115-151.  With DEFER a
+// ray that reaches a mesh leaf of the TLAS reports (deferred, deferred_obj) instead of entering the BLAS.
+template <bool USE_BVH, bool DEFER>
+__device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, const RngKey &key, int segment,
+                                            uint32_t *my_stack, uint32_t *blas_stack, float &best_t, uint32_t &best_obj,
+                                            uint32_t &best_prim, bool &deferred, uint32_t &deferred_obj) {
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    if (!USE_BVH) {
+        // scene.rs:137-149: linear scan with narrowing; a later object replaces on t <= closest
+        for (uint32_t k = 0; k < sc.n_objects; k++) {
+            Obj o = load_obj(sc.obj, k);     // wave-uniform index: scalar loads
+            float t; uint32_t prim;
+            if (hit_object(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+        }
+    } else {
+        // bvh.rs:88-98,115-151 over RenderObjectInternal items; same front-to-back scheme as hit_mesh
+        V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+        const uint32_t dir_neg = (r.d.x >= 0.f ? 0u : 1u) | (r.d.y >= 0.f ? 0u : 2u) | (r.d.z >= 0.f ? 0u : 4u);
+        LdsStack st{my_stack, 0};
+        bool have = false;
+        const uint32_t DONE = 0xffffffffu;
+        uint32_t node = 0;
+        while (node != DONE) {
+            // while-while: walk inner nodes until this lane holds a leaf (or is out of tree); the lanes then
+            // run their object tests together (part2: 21 % of lanes were active in the interleaved form)
+            uint32_t leafA = 0, leafB = 0; bool got_leaf = false;
+            while (node != DONE) {
+                float4 lo = sc.tlas[2 * (size_t)node], hi = sc.tlas[2 * (size_t)node + 1];
+                bool hitb = hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX);
+                uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
+                if (hitb && (A >> 30) == 0u) {
+                    bool left_first = ((dir_neg >> (B & 3u)) & 1u) == 0u;
+                    uint32_t left = node + 1, right = A & NODE_MASK;
+                    st.push(left_first ? right : left);
+                    node = left_first ? left : right;
+                    continue;
+                }
+                node = st.sp ? st.pop() : DONE;
+                if (hitb) { leafA = A; leafB = B; got_leaf = true; break; }
+            }
+            if (got_leaf) {
+                uint32_t items[2] = {leafA & NODE_MASK, leafB};
+                int n_items = ((leafA >> 30) == NODE_DOUBLE) ? 2 : 1;
+                for (int qq = 0; qq < n_items; qq++) {
+                    Obj o = load_obj_for_hit(sc.obj, items[qq]);
+                    if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)items[qq]], sc.obj_gate[2 * (size_t)items[qq] + 1], r.o, inv, TMIN, TMAX)) continue;
+                    if (DEFER && sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = items[qq]; continue; }   // park the first mesh
+                    float t; uint32_t prim;
+                    if (hit_object(sc, o, items[qq], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+                        if (!have || t < best_t || (t == best_t && sc.obj_rank[items[qq]] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = items[qq]; best_prim = prim; }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool USE_BVH>
 __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits,
                                                   DQueue q, int segment, int tlas_levels, int stack_levels) {
@@ -608,54 +667,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
             Ray r{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
             RngKey key{0, 0, 0};
             if (sc.has_medium) key = key_of(f, __float_as_uint(in.state[i].w));
-            if (!USE_BVH) {
-                // scene.rs:137-149: linear scan with narrowing; a later object replaces on t <= closest
-                for (uint32_t k = 0; k < sc.n_objects; k++) {
-                    Obj o = load_obj(sc.obj, k);     // wave-uniform index: scalar loads
-                    float t; uint32_t prim;
-                    if (hit_object(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
-                }
-            } else {
-                // bvh.rs:88-98,115-151 over RenderObjectInternal items; same front-to-back scheme as hit_mesh
-                V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
-                const uint32_t dir_neg = (r.d.x >= 0.f ? 0u : 1u) | (r.d.y >= 0.f ? 0u : 2u) | (r.d.z >= 0.f ? 0u : 4u);
-                LdsStack st{my_stack, 0};
-                bool have = false;
-                const uint32_t DONE = 0xffffffffu;
-                uint32_t node = 0;
-                while (node != DONE) {
-                    // while-while: walk inner nodes until this lane holds a leaf (or is out of tree); the lanes then
-                    // run their object tests together (part2: 21 % of lanes were active in the interleaved form)
-                    uint32_t leafA = 0, leafB = 0; bool got_leaf = false;
-                    while (node != DONE) {
-                        float4 lo = sc.tlas[2 * (size_t)node], hi = sc.tlas[2 * (size_t)node + 1];
-                        bool hitb = hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX);
-                        uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
-                        if (hitb && (A >> 30) == 0u) {
-                            bool left_first = ((dir_neg >> (B & 3u)) & 1u) == 0u;
-                            uint32_t left = node + 1, right = A & NODE_MASK;
-                            st.push(left_first ? right : left);
-                            node = left_first ? left : right;
-                            continue;
-                        }
-                        node = st.sp ? st.pop() : DONE;
-                        if (hitb) { leafA = A; leafB = B; got_leaf = true; break; }
-                    }
-                    if (got_leaf) {
-                        uint32_t items[2] = {leafA & NODE_MASK, leafB};
-                        int n_items = ((leafA >> 30) == NODE_DOUBLE) ? 2 : 1;
-                        for (int qq = 0; qq < n_items; qq++) {
-                            Obj o = load_obj_for_hit(sc.obj, items[qq]);
-                            if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)items[qq]], sc.obj_gate[2 * (size_t)items[qq] + 1], r.o, inv, TMIN, TMAX)) continue;
-                            if (sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = items[qq]; continue; }   // park the first mesh
-                            float t; uint32_t prim;
-                            if (hit_object(sc, o, items[qq], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
-                                if (!have || t < best_t || (t == best_t && sc.obj_rank[items[qq]] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = items[qq]; best_prim = prim; }
-                            }
-                        }
-                    }
-                }
-            }
+            closest_hit<USE_BVH, USE_BVH>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj);
             if (!deferred) hits[i] = pack_hit(best_t, best_obj, best_prim, sc.prim_bits);
         }
         if (USE_BVH && sc.has_mesh) {
@@ -893,6 +905,67 @@ __device__ __forceinline__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, c
 // suzanne, hdri, volume), which turns those fetches into ~64-cycle ds_reads; materials whose texture is a
 // ConstantTexture carry the colour inline, removing the third level entirely.
 // ------------------------------------------------------------------------------------------------
+// One path at its hit (or miss): emission / environment for paths that end here (written to sample_rad, every
+// path writes exactly once), the scattered ray and throughput for those that continue (render.rs:19-31).
+__device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, const float4 *objp, const float4 *matp,
+                                           const float4 *texp, const Ray &r, V3 beta, uint32_t path_id, float t_hit,
+                                           uint32_t hit_code, int segment, float4 *__restrict__ sample_rad, Ray &nr, V3 &nbeta) {
+    bool alive = false;
+    const uint32_t obj_index = hit_code == MISS ? MISS : (hit_code >> sc.prim_bits);
+    V3 rad = mk(0.f, 0.f, 0.f);
+    if (obj_index == MISS) {
+        // render.rs:31; ColorEnv ignores the direction, so its normalisation (sqrt + 3 divisions) is skipped
+        V3 dir = sc.env.kind == 0 ? r.d : normalized(r.d);
+        rad = beta * env_sample(sc.env, dir);
+    } else {
+        Obj o = load_obj(objp, obj_index);
+        float4 m0 = matp[2 * o.material], m1 = matp[2 * o.material + 1];
+        uint32_t mbits = __float_as_uint(m0.x), mkind = mbits & 0xffu, mtex = __float_as_uint(m0.y);
+        bool need_uv = (mbits & MF_NEEDS_UV) != 0, tex_const = (mbits & MF_TEX_CONST) != 0;
+        HitInfo h = rebuild_hit(sc, o, r, t_hit, hit_code & ((1u << sc.prim_bits) - 1u), need_uv);
+        V3 texc = mk(m1.x, m1.y, m1.z);                                      // inline ConstantTexture / Metal albedo
+        if (!tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
+        if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
+            rad = beta * texc;
+        } else if (segment < 10) {                                             // render.rs:21
+            RngKey key = key_of(f, path_id);
+            V3 atten = texc;
+            switch (mkind) {
+            case 0: {                                                          // Lambertian material.rs:64-75
+                V3 target = h.point + h.normal + random_in_unit_sphere(key, segment);
+                nr = Ray{h.point, target - h.point};
+                alive = true; break; }
+            case 1: {                                                          // Metal material.rs:90-107
+                V3 reflected = reflect(r.d, h.normal);
+                nr = Ray{h.point, reflected + m0.z * random_in_unit_sphere(key, segment)};
+                alive = dot(nr.d, h.normal) > 0.f; break; }
+            case 2: {                                                          // Dielectric material.rs:121-151
+                float ref_idx = m0.w;
+                V3 reflected = reflect(r.d, h.normal);
+                V3 outward; float ni_over_nt, cosine;
+                float ddn = dot(r.d, h.normal);
+                if (ddn > 0.f) { outward = -h.normal; ni_over_nt = ref_idx; cosine = fdiv(ref_idx * ddn, mag(r.d)); }
+                else { outward = h.normal; ni_over_nt = fdiv(1.0f, ref_idx); cosine = fdiv(-ddn, mag(r.d)); }
+                atten = mk(1.f, 1.f, 1.f);
+                V3 refracted; bool took_refraction = false;
+                if (refract(r.d, outward, ni_over_nt, refracted)) {
+                    float xi = u2f(draw(key, P_FRESNEL, segment, 0).x);
+                    if (xi > schlick(cosine, ref_idx)) { nr = Ray{h.point, refracted}; took_refraction = true; }
+                }
+                if (!took_refraction) nr = Ray{h.point, reflected};
+                alive = true; break; }
+            case 4: {                                                          // Isotropic material.rs:197-204
+                nr = Ray{h.point, random_in_unit_sphere(key, segment)};
+                alive = true; break; }
+            default: break;
+            }
+            nbeta = beta * atten;
+        }
+    }
+    if (!alive) sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, 0.f);   // every path writes exactly once
+    return alive;
+}
+
 extern __shared__ float4 lds_tables[];
 
 template <bool LDS_TAB>
@@ -928,60 +1001,70 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
             V3 beta = mk(st.x, st.y, st.z);
             path_id = __float_as_uint(st.w);
             const uint32_t hit_code = __float_as_uint(hr.y);
-            const uint32_t obj_index = hit_code == MISS ? MISS : (hit_code >> sc.prim_bits);
-            V3 rad = mk(0.f, 0.f, 0.f);
-            if (obj_index == MISS) {
-                // render.rs:31; ColorEnv ignores the direction, so its normalisation (sqrt + 3 divisions) is skipped
-                V3 dir = sc.env.kind == 0 ? r.d : normalized(r.d);
-                rad = beta * env_sample(sc.env, dir);
-            } else {
-                Obj o = load_obj(objp, obj_index);
-                float4 m0 = matp[2 * o.material], m1 = matp[2 * o.material + 1];
-                uint32_t mbits = __float_as_uint(m0.x), mkind = mbits & 0xffu, mtex = __float_as_uint(m0.y);
-                bool need_uv = (mbits & MF_NEEDS_UV) != 0, tex_const = (mbits & MF_TEX_CONST) != 0;
-                HitInfo h = rebuild_hit(sc, o, r, hr.x, hit_code & ((1u << sc.prim_bits) - 1u), need_uv);
-                V3 texc = mk(m1.x, m1.y, m1.z);                                      // inline ConstantTexture / Metal albedo
-                if (!tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
-                if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
-                    rad = beta * texc;
-                } else if (segment < 10) {                                             // render.rs:21
-                    RngKey key = key_of(f, path_id);
-                    V3 atten = texc;
-                    switch (mkind) {
-                    case 0: {                                                          // Lambertian material.rs:64-75
-                        V3 target = h.point + h.normal + random_in_unit_sphere(key, segment);
-                        nr = Ray{h.point, target - h.point};
-                        alive = true; break; }
-                    case 1: {                                                          // Metal material.rs:90-107
-                        V3 reflected = reflect(r.d, h.normal);
-                        nr = Ray{h.point, reflected + m0.z * random_in_unit_sphere(key, segment)};
-                        alive = dot(nr.d, h.normal) > 0.f; break; }
-                    case 2: {                                                          // Dielectric material.rs:121-151
-                        float ref_idx = m0.w;
-                        V3 reflected = reflect(r.d, h.normal);
-                        V3 outward; float ni_over_nt, cosine;
-                        float ddn = dot(r.d, h.normal);
-                        if (ddn > 0.f) { outward = -h.normal; ni_over_nt = ref_idx; cosine = fdiv(ref_idx * ddn, mag(r.d)); }
-                        else { outward = h.normal; ni_over_nt = fdiv(1.0f, ref_idx); cosine = fdiv(-ddn, mag(r.d)); }
-                        atten = mk(1.f, 1.f, 1.f);
-                        V3 refracted; bool took_refraction = false;
-                        if (refract(r.d, outward, ni_over_nt, refracted)) {
-                            float xi = u2f(draw(key, P_FRESNEL, segment, 0).x);
-                            if (xi > schlick(cosine, ref_idx)) { nr = Ray{h.point, refracted}; took_refraction = true; }
-                        }
-                        if (!took_refraction) nr = Ray{h.point, reflected};
-                        alive = true; break; }
-                    case 4: {                                                          // Isotropic material.rs:197-204
-                        nr = Ray{h.point, random_in_unit_sphere(key, segment)};
-                        alive = true; break; }
-                    default: break;
-                    }
-                    nbeta = beta * atten;
-                }
-            }
-            if (!alive) sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, 0.f);   // every path writes exactly once
+            alive = shade_path(sc, f, objp, matp, texp, r, beta, path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta);
         }
         // ---- K7: compaction inside the wave's private queue: ballot -> mbcnt prefix -> dense stores --------
+        unsigned long long mask = __ballot(alive);
+        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        if (alive) {
+            uint32_t dst = base + out_n + rank;
+            out.ray_a[dst] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x);
+            out.ray_b[dst] = make_float2(nr.d.y, nr.d.z);
+            out.state[dst] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id));
+        }
+        out_n += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 + K5 + K7 in one launch per segment ("bounce"): every lane intersects its ray and shades the hit while it
+// is still in registers, so the hit record and the second read of the ray never touch HBM (80 B per ray
+// instead of 120) and the VALU-bound intersection of one wave overlaps the HBM-bound state streaming of the
+// others on the same CU.  Same device functions as k_extend / k_shade, hence the same bits.  Not used when a
+// TLAS holds meshes (those rays are parked and finish out of order, see k_extend).
+// Dynamic LDS: [tables (LDS_TAB)] [traversal stacks (USE_BVH)].
+// ------------------------------------------------------------------------------------------------
+template <bool USE_BVH, bool LDS_TAB>
+__global__ __launch_bounds__(WB) void k_bounce(DScene sc, DFrame f, DPaths in, DPaths out, float4 *__restrict__ sample_rad,
+                                                  DQueue q, int segment, int tlas_levels, uint32_t n_mat, uint32_t n_tex,
+                                                  uint32_t table_quads) {
+    const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
+    const float4 *objp = sc.obj, *matp = sc.mat, *texp = sc.tex;
+    if (LDS_TAB) {
+        const uint32_t no = sc.n_objects * OBJ_Q, nm = 2 * n_mat, nt = 2 * n_tex;
+        for (uint32_t k = threadIdx.x; k < no; k += WB) lds_tables[k] = sc.obj[k];
+        for (uint32_t k = threadIdx.x; k < nm; k += WB) lds_tables[no + k] = sc.mat[k];
+        for (uint32_t k = threadIdx.x; k < nt; k += WB) lds_tables[no + nm + k] = sc.tex[k];
+        __syncthreads();
+        objp = lds_tables; matp = lds_tables + no; texp = lds_tables + no + nm;
+    }
+    if (w >= q.n_waves) return;
+    uint32_t *my_stack = reinterpret_cast<uint32_t *>(lds_tables + table_quads) + threadIdx.x;   // [level][lane]
+    uint32_t *blas_stack = my_stack + (size_t)tlas_levels * WB;
+    const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w];
+    const uint32_t base = w * q.cap;
+    uint32_t out_n = 0;
+    float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n; float2 rb_n = make_float2(0, 0);
+    if (lane < n) { ra_n = in.ray_a[base + lane]; rb_n = in.ray_b[base + lane]; st_n = in.state[base + lane]; }
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const uint32_t j = c0 + lane;
+        const uint32_t i = base + j;
+        float4 ra = ra_n, st = st_n; float2 rb = rb_n;
+        if (j + 64u < n) { ra_n = in.ray_a[i + 64u]; rb_n = in.ray_b[i + 64u]; st_n = in.state[i + 64u]; }
+        bool alive = false;
+        Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
+        if (j < n) {
+            Ray r{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
+            path_id = __float_as_uint(st.w);
+            RngKey key{0, 0, 0};
+            if (sc.has_medium) key = key_of(f, path_id);
+            float best_t = 2e9f; uint32_t best_obj = MISS, best_prim = 0;
+            bool deferred = false; uint32_t deferred_obj = 0;
+            closest_hit<USE_BVH, false>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj);
+            const uint32_t hit_code = best_obj == MISS ? MISS : ((best_obj << sc.prim_bits) | best_prim);
+            alive = shade_path(sc, f, objp, matp, texp, r, mk(st.x, st.y, st.z), path_id, best_t, hit_code, segment, sample_rad, nr, nbeta);
+        }
         unsigned long long mask = __ballot(alive);
         uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (alive) {
@@ -1091,6 +1174,21 @@ void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths 
         hipLaunchKernelGGL(k_shade<true>, wave_grid(c), dim3(WB), tab, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
     else
         hipLaunchKernelGGL(k_shade<false>, wave_grid(c), dim3(WB), 0, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
+}
+void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, float4 *sample_rad,
+                   int segment, bool use_bvh) {
+    size_t tab = ((size_t)sc.n_objects * OBJ_Q + 2 * (size_t)c.n_mat + 2 * (size_t)c.n_tex) * sizeof(float4);
+    const bool lds_tab = c.lds_tables && tab <= LDS_TABLE_LIMIT;
+    if (!lds_tab) tab = 0;
+    int tl = use_bvh ? c.tlas_depth + 1 : 0;
+    int levels = tl + c.blas_depth + 1;
+    size_t lds = tab + (size_t)levels * WB * sizeof(uint32_t);
+    uint32_t tq = (uint32_t)(tab / sizeof(float4));
+    dim3 g = wave_grid(c);
+#define FW_BOUNCE(B, T) hipLaunchKernelGGL((k_bounce<B, T>), g, dim3(WB), lds, c.stream, sc, f, in, out, sample_rad, c.q, segment, tl, c.n_mat, c.n_tex, tq)
+    if (use_bvh) { if (lds_tab) FW_BOUNCE(true, true); else FW_BOUNCE(true, false); }
+    else { if (lds_tab) FW_BOUNCE(false, true); else FW_BOUNCE(false, false); }
+#undef FW_BOUNCE
 }
 void launch_queue_totals(const LaunchCfg &c, uint32_t *totals) {
     hipLaunchKernelGGL(k_queue_totals, dim3(32, MAX_SEGMENTS), dim3(BLOCK), 0, c.stream, c.q, totals);   // totals are zeroed per frame

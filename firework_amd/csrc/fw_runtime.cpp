@@ -728,6 +728,11 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         while (ev.size() < want) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ev.push_back(e); }
     }
     const bool use_bvh = p->use_bvh != 0;
+    // FIREWORK_FUSED=1: one launch per segment (k_bounce = intersect + shade in registers, 80 instead of 120 B per ray).
+    // Off by default: the frame is VALU-bound, not HBM-bound, and the fused kernel's lower occupancy costs more than the
+    // bytes save (cornell 62.0 vs 55.5 ms, hdri 35.5 vs 38.5 ms, 1/8-frame shares 9.2 vs 8.3 ms).  Never with parked mesh rays.
+    const char *fe = getenv("FIREWORK_FUSED");
+    const bool fused = fe && atoi(fe) != 0 && !(use_bvh && cfg.has_mesh);
 
     HIPCHK(hipEventRecord(ws->events[0], stream));
     if (n_lanes > 1) {     // fork: the lane streams start after everything queued on the caller's stream so far
@@ -756,8 +761,11 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         int cur = 0;
         timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], n_paths); });
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
-            timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh); });
-            timed(2, [&] { fw::launch_shade(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], hits, srad, seg); });
+            if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
+            else {
+                timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh); });
+                timed(2, [&] { fw::launch_shade(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], hits, srad, seg); });
+            }
             cur ^= 1;
         }
         timed(3, [&] { fw::launch_queue_totals(cfg, totals); });
@@ -801,7 +809,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
                 }
             stats->ms_raygen = acc[0]; stats->ms_extend = acc[1]; stats->ms_shade = acc[2]; stats->ms_accumulate = acc[3];
         }
-        stats->n_extend_launches = n_batches * fw::MAX_SEGMENTS; stats->n_shade_launches = n_batches * fw::MAX_SEGMENTS;
+        stats->n_extend_launches = fused ? 0 : n_batches * fw::MAX_SEGMENTS; stats->n_shade_launches = n_batches * fw::MAX_SEGMENTS;
         stats->n_batches = n_batches; stats->tlas_nodes = sc->tlas_nodes; stats->blas_nodes = sc->blas_nodes;
         stats->reserved = (sc->tlas_depth << 16) | sc->blas_depth;   // depths of the trees actually walked
     }

@@ -8,15 +8,33 @@ An N-rank render is therefore bit-identical to a 1-rank render.
 """
 import numpy as np
 
-TILE = 32
+import os
+TILE = int(os.environ.get("FW_TILE", "16"))
 
 
-def tile_pixel_ids(width, height, rank, world, tile=TILE):
-    """Linear pixel indices (render.rs:127 `idx`) of the tiles owned by `rank`: tiles are numbered
-    row-major and dealt round-robin, which balances cheap (sky/black) and expensive rows."""
+def tile_owner(t, tx, world, scheme="diagonal"):
+    """Rank that renders tile t (tiles numbered row-major, tx per row).
+    "roundrobin": t % world — degenerates into vertical stripes whenever world divides tx (16 tiles per row of a
+    512-wide frame and 2/4/8 ranks), which loads ranks unevenly on scenes with vertical structure (cornell's walls).
+    "diagonal": each tile row is shifted by one more rank, so every rank's tiles spread over both axes."""
+    if scheme == "roundrobin":
+        return t % world
+    if scheme == "diagonal":
+        return (t % tx + t // tx) % world
+    if scheme == "hash":
+        h = (t * 0x9E3779B1) & 0xFFFFFFFF
+        h ^= h >> 15; h = (h * 0x85EBCA6B) & 0xFFFFFFFF; h ^= h >> 13
+        return h % world
+    raise ValueError(scheme)
+
+
+def tile_pixel_ids(width, height, rank, world, tile=TILE, scheme="diagonal"):
+    """Linear pixel indices (render.rs:127 `idx`) of the tiles owned by `rank` (see tile_owner)."""
     tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
     ids = []
-    for t in range(rank, tx * ty, world):
+    for t in range(tx * ty):
+        if tile_owner(t, tx, world, scheme) != rank:
+            continue
         y0, x0 = (t // tx) * tile, (t % tx) * tile
         ys = np.arange(y0, min(y0 + tile, height), dtype=np.uint32)
         xs = np.arange(x0, min(x0 + tile, width), dtype=np.uint32)

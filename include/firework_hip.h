@@ -213,7 +213,8 @@ typedef struct fw_stats {
     double ms_scene;                         /* host: flatten + BVH build + upload (one-shot call only)      */
     double ms_render;                        /* device: first launch to last, HIP events on the launch stream */
     double ms_raygen, ms_extend, ms_shade, ms_accumulate; /* per-kernel-class device time (HIP events) */
-    uint32_t n_extend_launches, n_shade_launches, n_batches;
+    uint32_t n_extend_launches, n_shade_launches, n_batches;  /* FIREWORK_FUSED=1: no extend launches, the fused
+                                                                 intersect+shade launches are counted and timed as shade */
     uint32_t tlas_nodes, blas_nodes;
     uint32_t reserved;
 } fw_stats;

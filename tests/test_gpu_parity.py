@@ -187,6 +187,20 @@ def test_batching_and_pixel_subsets_are_bit_identical(oracle):
     assert np.array_equal(out, full.linear)
 
 
+def test_fused_bounce_kernel_is_bit_identical_to_the_split_kernels(monkeypatch):
+    """FIREWORK_FUSED=1 intersects and shades in one launch per segment (k_bounce) with the device functions of
+    k_extend / k_shade: same bits, same ray counts, linear scan and TLAS."""
+    for name, bvh in (("C2_cornell_box", False), ("C2_cornell_box", True), ("C4b_volume_test", False), ("C1_random_spheres", True)):
+        s, r = scenes.config(name, 48, 40, 12)
+        r.use_bvh(bvh)
+        monkeypatch.delenv("FIREWORK_FUSED", raising=False)
+        split = r.render_full(s)
+        monkeypatch.setenv("FIREWORK_FUSED", "1")
+        fused = r.render_full(s)
+        assert fused.stats["n_extend_launches"] == 0 and split.stats["n_extend_launches"] > 0
+        assert np.array_equal(split.linear, fused.linear) and split.stats["rays"] == fused.stats["rays"]
+
+
 def test_errors_cross_the_abi_as_codes():
     from firework_amd import _abi as A
     r = Renderer.default().width(8).height(8).samples(1)

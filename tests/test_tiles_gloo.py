@@ -21,6 +21,20 @@ def test_tiles_partition_the_frame(w, h, world, tile):
         assert len({p.shape[0] for p in parts}) == 1      # BASELINE config: perfectly even
 
 
+@pytest.mark.parametrize("scheme", ["diagonal", "roundrobin", "hash"])
+def test_every_dealing_scheme_partitions_and_diagonal_spreads_over_both_axes(scheme):
+    w = h = 512
+    for world in (2, 4, 8):
+        parts = [tile_pixel_ids(w, h, r, world, 16, scheme) for r in range(world)]
+        assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(w * h))
+        if scheme == "diagonal":     # the default: equal shares, and every rank owns tiles in every tile row AND column
+            assert len({p.shape[0] for p in parts}) == 1
+            for p in parts:
+                assert len(np.unique((p % w) // 16)) == w // 16 and len(np.unique((p // w) // 16)) == h // 16
+        if scheme == "roundrobin":   # why it is not the default: vertical stripes when world divides the tiles per row
+            assert len(np.unique((parts[0] % w) // 16)) == (w // 16) // world
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

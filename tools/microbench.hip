@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #define N_ITER 2048
+typedef float f2 __attribute__((ext_vector_type(2)));
 template <int OP> __global__ void k(uint32_t *out, uint32_t seed, float fs) {
     uint32_t a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u, c = b + 77u, d = c * 3u;
     float x = fs + threadIdx.x, y = x * 1.0001f, z = y + 0.5f, w = z * 0.999f;
@@ -19,6 +20,9 @@ template <int OP> __global__ void k(uint32_t *out, uint32_t seed, float fs) {
         if (OP == 6) { x = sqrtf(x + 1.f); y = sqrtf(y + 1.f); z = sqrtf(z + 1.f); w = sqrtf(w + 1.f); }
         if (OP == 7) { a = __umulhi(a, 0xD2511F53u) ^ b; b = __umulhi(b, 0xCD9E8D57u) ^ c; c = __umulhi(c, 0xD2511F53u) ^ d; d = __umulhi(d, 0xCD9E8D57u) ^ a; }
         if (OP == 8) { a ^= a >> 16; b ^= b >> 15; c ^= c >> 13; d ^= d >> 16; a += b; b += c; c += d; d += a; }  // cheap int ops (2 per lane-op)
+        if (OP == 10) { f2 p = {x, y}, q = {z, w}; p = __builtin_elementwise_fma(p, f2{1.0001f, 1.0001f}, f2{0.5f, 0.5f}); q = __builtin_elementwise_fma(q, f2{1.0001f, 1.0001f}, f2{0.5f, 0.5f}); x = p.x; y = p.y; z = q.x; w = q.y; }   // v_pk_fma_f32 x2 = 4 fma
+        if (OP == 11) { f2 p = {x, y}, q = {z, w}; p = p * f2{1.0001f, 1.0001f}; q = q * f2{0.9999f, 0.9999f}; p = p + f2{0.5f, 0.5f}; q = q + f2{0.5f, 0.5f}; x = p.x; y = p.y; z = q.x; w = q.y; }   // v_pk_mul + v_pk_add x2
+        if (OP == 12) { x = x * 1.0001f; y = y * 1.0001f; z = z * 0.9999f; w = w * 0.9999f; x = x + 0.5f; y = y + 0.5f; z = z + 0.5f; w = w + 0.5f; }   // scalar mul + add x4
         if (OP == 9) { x = __builtin_amdgcn_rcpf(x) + 1.f; y = __builtin_amdgcn_rcpf(y) + 1.f; z = __builtin_amdgcn_rcpf(z) + 1.f; w = __builtin_amdgcn_rcpf(w) + 1.f; }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ __float_as_uint(x + y + z + w);
@@ -42,5 +46,6 @@ int main() {
     run<0>("fma_f32 x4", 4); run<1>("mul_lo_u32 x4", 4); run<2>("mad u32 (a*b+c) x4", 4); run<3>("mad_u32_u24 x4", 4);
     run<4>("IEEE div x4", 4); run<5>("mul * frcp_rn x4", 4); run<6>("sqrtf x4", 4); run<7>("mul_hi_u32 ^ x4", 4); run<8>("xorshift+add x8", 8);
     run<9>("v_rcp_f32 + add x4", 4);
+    run<10>("v_pk_fma_f32 x2 (4 fma)", 2); run<11>("v_pk_mul+v_pk_add x2 (8 flop-ops)", 4); run<12>("mul + add x4 unpacked (8 ops)", 8);
     return 0;
 }
