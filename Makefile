@@ -3,9 +3,11 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 # -ffp-contract=off: float expressions round exactly as written, on the device AND in the host-side
 # scene/camera code, so hit/miss decisions follow the CPU oracle bit for bit.
-HIPFLAGS ?= -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=$(ARCH) -Wall -Wno-unused-function
+# -fno-slp-vectorize: packed f32 (v_pk_mul/add/fma) issues at half the rate of the scalar forms on gfx950
+# (tools/microbench.hip), so SLP-packed pairs gain nothing and their repacking v_movs cost: k_extend<false> 25.1 -> 20.3 ms.
+HIPFLAGS ?= -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=$(ARCH) -Wall -Wno-unused-function
 SRC = firework_amd/csrc/fw_kernels.hip firework_amd/csrc/fw_runtime.cpp
-HDR = firework_amd/csrc/fw_device.h include/firework_hip.h
+HDR = firework_amd/csrc/fw_device.h include/firework_hip.h Makefile
 LIB = firework_amd/lib/libfirework_hip.so
 
 all: $(LIB) oracle examples

@@ -157,6 +157,21 @@ __device__ __forceinline__ RngKey key_of(const DFrame &f, uint32_t path_id) {
 // K1  ray generation
 // ------------------------------------------------------------------------------------------------
 constexpr int WB = FW_WB;
+// Traversal statistics (debug builds only: make CXXFLAGS_EXTRA=-DFW_TRAV_STATS): per phase, useful lane-iterations and the
+// lane-slots the wave spent on them (64 per executed iteration) -> lane utilisation of the node walks and leaf tests.
+#ifdef FW_TRAV_STATS
+__device__ unsigned long long g_trav[8];
+__shared__ float g_ts[8 * 64];
+#define TS_TICK(k) do { float pc_ = (float)__popcll(__ballot(1)); g_ts[(k) * 64 + (threadIdx.x & 63u)] += 1.f; g_ts[((k) + 1) * 64 + (threadIdx.x & 63u)] += 64.f / pc_; } while (0)
+#define TS_BEGIN() do { for (int k_ = 0; k_ < 8; k_++) g_ts[k_ * 64 + (threadIdx.x & 63u)] = 0.f; } while (0)
+#define TS_END() do { for (int k_ = 0; k_ < 8; k_++) { float v_ = g_ts[k_ * 64 + (threadIdx.x & 63u)]; for (int o_ = 32; o_ > 0; o_ >>= 1) v_ += __shfl_xor(v_, o_); \
+                      if ((threadIdx.x & 63u) == 0) atomicAdd(&g_trav[k_], (unsigned long long)(v_ + 0.5f)); } } while (0)
+#else
+#define TS_TICK(k) do { } while (0)
+#define TS_BEGIN() do { } while (0)
+#define TS_END() do { } while (0)
+#endif
+
 __device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (WB / 64) + (threadIdx.x >> 6); }
 
 // Hit record: 8 bytes (t, code) with code = object << prim_bits | primitive (rect3d face / mesh triangle), MISS = all
@@ -473,6 +488,7 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
         // do the lanes test triangles, together — the long triangle test is not run for one or two lanes at a time
         uint32_t leafA = 0, leafB = 0; bool got_leaf = false;
         while (node != DONE) {
+            TS_TICK(4);
             float4 lo = sc.blas[2 * (size_t)node], hi = sc.blas[2 * (size_t)node + 1];
             // cull_t: a t the caller already holds from another object (hits beyond it cannot win; equal t still can)
             bool hit = hit_aabb(lo, hi, r.o, inv, tmin, have ? fminf(best, cull_t) : cull_t);
@@ -491,6 +507,7 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
             uint32_t items[2] = {leafA & NODE_MASK, leafB};
             int n_items = ((leafA >> 30) == NODE_DOUBLE) ? 2 : 1;
             for (int q = 0; q < n_items; q++) {
+                TS_TICK(6);
                 const float4 *tp = sc.tri + 3 * (size_t)(tri_base + items[q]);
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, b0, b1, b2;
@@ -589,6 +606,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
             // run their object tests together (part2: 21 % of lanes were active in the interleaved form)
             uint32_t leafA = 0, leafB = 0; bool got_leaf = false;
             while (node != DONE) {
+                TS_TICK(0);
                 float4 lo = sc.tlas[2 * (size_t)node], hi = sc.tlas[2 * (size_t)node + 1];
                 bool hitb = hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX);
                 uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
@@ -609,6 +627,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
                     Obj o = load_obj_for_hit(sc.obj, items[qq]);
                     if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)items[qq]], sc.obj_gate[2 * (size_t)items[qq] + 1], r.o, inv, TMIN, TMAX)) continue;
                     if (DEFER && sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = items[qq]; continue; }   // park the first mesh
+                    TS_TICK(2);
                     float t; uint32_t prim;
                     if (hit_object(sc, o, items[qq], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
                         if (!have || t < best_t || (t == best_t && sc.obj_rank[items[qq]] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = items[qq]; best_prim = prim; }
@@ -624,6 +643,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
                                                   DQueue q, int segment, int tlas_levels, int stack_levels) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     if (w >= q.n_waves) return;
+    TS_BEGIN();
     const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w];
     const uint32_t base = w * q.cap;
     uint32_t *my_stack = lds_stack + threadIdx.x;                    // [level][lane]
@@ -684,6 +704,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
         }
     }
     if (USE_BVH && list_n) flush(0u, list_n);
+    TS_END();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1093,11 +1114,23 @@ __global__ __launch_bounds__(BLOCK) void k_queue_totals(DQueue q, uint32_t *tota
 // ------------------------------------------------------------------------------------------------
 // K8  accumulate (sample order, deterministic) and resolve
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_accumulate(DFrame f, const float4 *__restrict__ sample_rad, float4 *__restrict__ accum) {
-    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < f.n_pixels; p += gridDim.x * BLOCK) {
+// One thread per pixel sums its samples in sample order (the reference's order; float addition does not reassociate).
+// Single-wave workgroups and 16 loads in flight per thread keep a 1/8-frame tile share (32 Ki pixels = 512 waves for
+// 1024 SIMDs) near the HBM rate: 0.49 -> see DESIGN §7.
+__global__ __launch_bounds__(WB) void k_accumulate(DFrame f, const float4 *__restrict__ sample_rad, float4 *__restrict__ accum) {
+    for (uint32_t p = blockIdx.x * WB + threadIdx.x; p < f.n_pixels; p += gridDim.x * WB) {
         float4 a = accum[p];
-        for (uint32_t s = 0; s < f.spp_batch; s++) {            // render.rs:181: total_color += color(...)
-            float4 c = sample_rad[(size_t)s * f.n_pixels + p];
+        const float4 *src = sample_rad + p;
+        uint32_t s = 0;
+        for (; s + 16u <= f.spp_batch; s += 16u) {
+            float4 c[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) c[k] = src[(size_t)(s + k) * f.n_pixels];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { a.x += c[k].x; a.y += c[k].y; a.z += c[k].z; }   // render.rs:181: total_color += color(...)
+        }
+        for (; s < f.spp_batch; s++) {
+            float4 c = src[(size_t)s * f.n_pixels];
             a.x += c.x; a.y += c.y; a.z += c.z;
         }
         accum[p] = a;
@@ -1190,11 +1223,19 @@ void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else { if (lds_tab) FW_BOUNCE(false, true); else FW_BOUNCE(false, false); }
 #undef FW_BOUNCE
 }
+#ifdef FW_TRAV_STATS
+extern "C" int fw_debug_trav_stats(unsigned long long out[8]) {   // debug builds only; reads and clears the counters
+    unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trav), sizeof zero) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trav), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
 void launch_queue_totals(const LaunchCfg &c, uint32_t *totals) {
     hipLaunchKernelGGL(k_queue_totals, dim3(32, MAX_SEGMENTS), dim3(BLOCK), 0, c.stream, c.q, totals);   // totals are zeroed per frame
 }
 void launch_accumulate(const LaunchCfg &c, const DFrame &f, const float4 *sample_rad, float4 *accum) {
-    hipLaunchKernelGGL(k_accumulate, dim3(c.blocks_other), dim3(BLOCK), 0, c.stream, f, sample_rad, accum);
+    uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)f.n_pixels + WB - 1) / WB, 65536));
+    hipLaunchKernelGGL(k_accumulate, dim3(blocks), dim3(WB), 0, c.stream, f, sample_rad, accum);
 }
 void launch_resolve(const LaunchCfg &c, const DFrame &f, const float4 *accum, uint32_t total_spp, float gamma,
                     uint8_t *rgb8, float *gamma_rgb, float *linear_rgb) {

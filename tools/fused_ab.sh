@@ -1,4 +1,6 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3 &&
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fused', d['value'], d['ms_per_step'], d['kernel_ms_per_step'])" &&
-FIREWORK_SPLIT=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('split', d['value'], d['ms_per_step'], d['kernel_ms_per_step'])" &&
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fused', d['value'], d['ms_per_step'], d['kernel_ms_per_step'])"
+# split kernels (default) vs FIREWORK_FUSED=1 (k_bounce), interleaved on one box
+p() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['kernel_ms_per_step'].items()})"; }
+for i in 1 2; do
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline $@ 2>/dev/null | p split
+FIREWORK_FUSED=1 python bench.py --steps 3 --warmup 1 --no-cpu-baseline $@ 2>/dev/null | p fused
+done

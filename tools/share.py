@@ -9,7 +9,7 @@ from firework_amd.tiles import TiledRenderer
 scene, renderer = scenes.config("C2_cornell_box", None, None, None)
 renderer.time_kernels(True)
 base = None
-for world in (1, 4, 8):
+for world in [int(x) for x in os.environ.get("SHARE_WORLDS", "1,2,4,8").split(",")]:
     tr = TiledRenderer(scene, renderer, 0, world, 0, dist=None)
     tr.tg.world = 1   # no collective: assemble() just scatters the local tiles
     tr.tg.all_ids_dev = [tr.tg.all_ids_dev[0]]
