@@ -94,13 +94,15 @@ struct DFrame {
     uint32_t spp_batch;           // samples per pixel in this batch
     float inv_width;              // 1.0f / width
     float inv_n_pixels;           // 1.0f / n_pixels (path_id -> sample index without an integer division)
+    uint32_t q_n_waves, q_shift;  // the batch's queue geometry (DQueue n_waves, cpw_shift): home slot <-> linear path id
+    uint32_t skip_zero_deposits;  // black environment: k_raygen zeroes the deposits, k_shade writes only non-zero radiance
 };
 
 // ---- wavefront path state, SoA over path slots (DESIGN.md §"Path state")
 struct DPaths {
     float4 *ray_a;   // (o.x o.y o.z d.x)
     float2 *ray_b;   // (d.y d.z)
-    float4 *state;   // (beta.r beta.g beta.b, bits path_id)
+    float4 *state;   // (beta.r beta.g beta.b, bits home slot = the path's slot in the segment-0 queue)
 };
 
 // wave-private queues: wave w owns slots [w*cap, (w+1)*cap) of every path array;
@@ -127,7 +129,7 @@ struct LaunchCfg {
 };
 constexpr size_t LDS_TABLE_LIMIT = 16 * 1024;   // object+material+texture tables up to this size are staged in LDS
 
-void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, uint32_t n_paths);
+void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, float4 *sample_rad, uint32_t n_paths);
 void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float2 *hits, int segment, bool use_bvh);
 void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment);

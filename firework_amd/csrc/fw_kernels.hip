@@ -139,11 +139,14 @@ __device__ __forceinline__ V3 random_in_unit_disk(const RngKey &k) {
     return p;
 }
 
-// path_id -> (pixel index as in render.rs:127, sample index).  path_id = s_local * n_pixels + p_local with
+// A path is named by its HOME SLOT: the slot k_raygen put it in, home = wave * cap + chunk * 64 + lane.  Its linear id
+// (chunk * n_waves + wave) * 64 + lane = s_local * n_pixels + p_local gives the pixel (render.rs:127) and the sample.
+// Radiance is deposited at sample_rad[home]: a wave's deposits stay inside its own 16 B * cap window instead of being
+// strewn over the whole [sample][pixel] array (k_shade 26.9 -> see DESIGN §5), and k_accumulate walks the same mapping.
 // s_local < 2^12, so a float quotient is off by at most one: fix it up instead of a 32-bit integer division.
-__device__ __forceinline__ RngKey key_of(const DFrame &f, uint32_t path_id) {
-    uint32_t s_local = (uint32_t)((float)path_id * f.inv_n_pixels);
-    int32_t p_local = (int32_t)(path_id - s_local * f.n_pixels);
+__device__ __forceinline__ RngKey key_of_linear(const DFrame &f, uint32_t linear) {
+    uint32_t s_local = (uint32_t)((float)linear * f.inv_n_pixels);
+    int32_t p_local = (int32_t)(linear - s_local * f.n_pixels);
     if (p_local < 0) { s_local--; p_local += (int32_t)f.n_pixels; }
     else if ((uint32_t)p_local >= f.n_pixels) { s_local++; p_local -= (int32_t)f.n_pixels; }
     RngKey k;
@@ -152,6 +155,31 @@ __device__ __forceinline__ RngKey key_of(const DFrame &f, uint32_t path_id) {
     k.seed32 = f.seed32;
     return k;
 }
+__device__ __forceinline__ RngKey key_of(const DFrame &f, uint32_t home) {
+    const uint32_t lane = home & 63u, c = (home >> 6) & ((1u << f.q_shift) - 1u), w = home >> (f.q_shift + 6u);
+    return key_of_linear(f, (c * f.q_n_waves + w) * 64u + lane);
+}
+
+// Streaming cache policy.  Every queue element is written once and read once, ~30 GB apart, and the radiance deposits
+// are scattered 16-byte pieces: with the `nt` bit these do not linger in L2 as partially filled lines
+// (k_shade 29.8 -> 25.5 ms for the deposits alone).  FW_NT_* switch the three classes for A/B runs.
+#ifndef FW_NT_RAD
+#define FW_NT_RAD 1
+#endif
+#ifndef FW_NT_ST
+#define FW_NT_ST 0
+#endif
+#ifndef FW_NT_LD
+#define FW_NT_LD 0
+#endif
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_nt(float4 *p, float4 v) { f4v x = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(x, reinterpret_cast<f4v *>(p)); }
+__device__ __forceinline__ void st_nt(float2 *p, float2 v) { f2v x = {v.x, v.y}; __builtin_nontemporal_store(x, reinterpret_cast<f2v *>(p)); }
+__device__ __forceinline__ float4 ld_nt(const float4 *p) { f4v x = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p)); return make_float4(x.x, x.y, x.z, x.w); }
+__device__ __forceinline__ float2 ld_nt(const float2 *p) { f2v x = __builtin_nontemporal_load(reinterpret_cast<const f2v *>(p)); return make_float2(x.x, x.y); }
+template <class T> __device__ __forceinline__ void qst(T *p, T v) { if (FW_NT_ST) st_nt(p, v); else *p = v; }
+template <class T> __device__ __forceinline__ T qld(const T *p) { if (FW_NT_LD) return ld_nt(p); return *p; }
 
 // ------------------------------------------------------------------------------------------------
 // K1  ray generation
@@ -182,7 +210,7 @@ __device__ __forceinline__ float2 pack_hit(float t, uint32_t obj, uint32_t prim,
 
 // Wave w generates the paths  id = chunk * (n_waves*64) + w*64 + lane  (chunks of 64 consecutive pixels of
 // one sample index, dealt round-robin to the waves: coherent inside a wave, balanced across waves).
-__global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out, DQueue q, uint32_t n_paths) {
+__global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out, float4 *__restrict__ sample_rad, DQueue q, uint32_t n_paths) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     if (w >= q.n_waves) return;
     const Rcp rw = make_rcp((float)f.width), rh = make_rcp((float)f.height);
@@ -192,7 +220,7 @@ __global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out
         if (id0 >= n_paths) break;
         uint32_t i = id0 + lane;
         if (i < n_paths) {
-            RngKey k = key_of(f, i);
+            RngKey k = key_of_linear(f, i);
             uint32_t py_row = (uint32_t)((float)k.pixel * f.inv_width);      // k.pixel / width without an integer division
             int32_t px = (int32_t)(k.pixel - py_row * f.width);
             if (px < 0) { py_row--; px += (int32_t)f.width; } else if ((uint32_t)px >= f.width) { py_row++; px -= (int32_t)f.width; }
@@ -207,9 +235,10 @@ __global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out
             V3 o = pos + offset;
             V3 d = ld3(cam.lower_left) + u * ld3(cam.horizontal) + v * ld3(cam.vertical) - pos - offset;
             uint32_t slot = w * q.cap + chunk * 64u + lane;
-            out.ray_a[slot] = make_float4(o.x, o.y, o.z, d.x);
-            out.ray_b[slot] = make_float2(d.y, d.z);
-            out.state[slot] = make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
+            qst(&out.ray_a[slot], make_float4(o.x, o.y, o.z, d.x));
+            qst(&out.ray_b[slot], make_float2(d.y, d.z));
+            qst(&out.state[slot], make_float4(1.f, 1.f, 1.f, __uint_as_float(slot)));
+            if (f.skip_zero_deposits) sample_rad[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // dense here, so k_shade can skip the scattered zeros
         }
         produced += min(64u, n_paths - id0);
     }
@@ -660,7 +689,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
             const uint32_t e = first + lane;
             const uint32_t slot = e_slot[e], obj = e_obj[e];
             float bt = e_t[e]; uint32_t bobj = e_bobj[e], bprim = e_bprim[e];
-            float4 ra = in.ray_a[slot]; float2 rb = in.ray_b[slot];
+            float4 ra = qld(&in.ray_a[slot]); float2 rb = qld(&in.ray_b[slot]);
             Ray world{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)};
             Obj o = load_obj(sc.obj, obj);
             Ray r = to_object_space(o, world);
@@ -668,18 +697,18 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
             if (hit_mesh(sc, o.aux0, o.aux1, r, TMIN, TMAX, bt, blas_stack, t, prim)) {
                 if (bobj == MISS || t < bt || (t == bt && sc.obj_rank[obj] > sc.obj_rank[bobj])) { bt = t; bobj = obj; bprim = prim; }
             }
-            hits[slot] = pack_hit(bt, bobj, bprim, sc.prim_bits);
+            qst(&hits[slot], pack_hit(bt, bobj, bprim, sc.prim_bits));
         }
     };
 
     // software pipeline: the next chunk's ray is requested before the current chunk is traversed
     float4 ra_n = make_float4(0, 0, 0, 0); float2 rb_n = make_float2(0, 0);
-    if (lane < n) { ra_n = in.ray_a[base + lane]; rb_n = in.ray_b[base + lane]; }
+    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = qld(&in.ray_b[base + lane]); }
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
         const uint32_t j = c0 + lane;
         const uint32_t i = base + j;
         float4 ra = ra_n; float2 rb = rb_n;
-        if (j + 64u < n) { ra_n = in.ray_a[i + 64u]; rb_n = in.ray_b[i + 64u]; }
+        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = qld(&in.ray_b[i + 64u]); }
         const bool active = j < n;
         bool deferred = false; uint32_t deferred_obj = 0;
         float best_t = TMAX; uint32_t best_obj = MISS, best_prim = 0;
@@ -688,7 +717,7 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
             RngKey key{0, 0, 0};
             if (sc.has_medium) key = key_of(f, __float_as_uint(in.state[i].w));
             closest_hit<USE_BVH, USE_BVH>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj);
-            if (!deferred) hits[i] = pack_hit(best_t, best_obj, best_prim, sc.prim_bits);
+            if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
         }
         if (USE_BVH && sc.has_mesh) {
             unsigned long long mask = __ballot(deferred);
@@ -983,7 +1012,12 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
             nbeta = beta * atten;
         }
     }
-    if (!alive) sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, 0.f);   // every path writes exactly once
+    // every path deposits exactly once — except zeros over a black environment: k_raygen has already written them, densely
+    // (adding +0 is exact, and most indoor paths end black; the scattered 16-byte deposits are k_shade's costliest stores)
+    if (!alive && !(f.skip_zero_deposits && rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
+        if (FW_NT_RAD) st_nt(&sample_rad[path_id], make_float4(rad.x, rad.y, rad.z, 0.f));
+        else sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, 0.f);
+    }
     return alive;
 }
 
@@ -1009,12 +1043,12 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     uint32_t out_n = 0;                                                  // survivors written so far (wave-uniform)
     // software pipeline: next chunk's ray / state / hit are in flight while the current chunk is shaded
     float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n; float2 rb_n = make_float2(0, 0), hr_n = rb_n;
-    if (lane < n) { ra_n = in.ray_a[base + lane]; rb_n = in.ray_b[base + lane]; st_n = in.state[base + lane]; hr_n = hits[base + lane]; }
+    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = qld(&in.ray_b[base + lane]); st_n = qld(&in.state[base + lane]); hr_n = qld(&hits[base + lane]); }
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
         const uint32_t j = c0 + lane;
         const uint32_t i = base + j;
         float4 ra = ra_n, st = st_n; float2 rb = rb_n, hr = hr_n;
-        if (j + 64u < n) { ra_n = in.ray_a[i + 64u]; rb_n = in.ray_b[i + 64u]; st_n = in.state[i + 64u]; hr_n = hits[i + 64u]; }
+        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = qld(&in.ray_b[i + 64u]); st_n = qld(&in.state[i + 64u]); hr_n = qld(&hits[i + 64u]); }
         bool alive = false;
         Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
         if (j < n) {
@@ -1029,9 +1063,9 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
         uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (alive) {
             uint32_t dst = base + out_n + rank;
-            out.ray_a[dst] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x);
-            out.ray_b[dst] = make_float2(nr.d.y, nr.d.z);
-            out.state[dst] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id));
+            qst(&out.ray_a[dst], make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x));
+            qst(&out.ray_b[dst], make_float2(nr.d.y, nr.d.z));
+            qst(&out.state[dst], make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id)));
         }
         out_n += (uint32_t)__popcll(mask);
     }
@@ -1067,12 +1101,12 @@ __global__ __launch_bounds__(WB) void k_bounce(DScene sc, DFrame f, DPaths in, D
     const uint32_t base = w * q.cap;
     uint32_t out_n = 0;
     float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n; float2 rb_n = make_float2(0, 0);
-    if (lane < n) { ra_n = in.ray_a[base + lane]; rb_n = in.ray_b[base + lane]; st_n = in.state[base + lane]; }
+    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = qld(&in.ray_b[base + lane]); st_n = qld(&in.state[base + lane]); }
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
         const uint32_t j = c0 + lane;
         const uint32_t i = base + j;
         float4 ra = ra_n, st = st_n; float2 rb = rb_n;
-        if (j + 64u < n) { ra_n = in.ray_a[i + 64u]; rb_n = in.ray_b[i + 64u]; st_n = in.state[i + 64u]; }
+        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = qld(&in.ray_b[i + 64u]); st_n = qld(&in.state[i + 64u]); }
         bool alive = false;
         Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
         if (j < n) {
@@ -1090,9 +1124,9 @@ __global__ __launch_bounds__(WB) void k_bounce(DScene sc, DFrame f, DPaths in, D
         uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (alive) {
             uint32_t dst = base + out_n + rank;
-            out.ray_a[dst] = make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x);
-            out.ray_b[dst] = make_float2(nr.d.y, nr.d.z);
-            out.state[dst] = make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id));
+            qst(&out.ray_a[dst], make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x));
+            qst(&out.ray_b[dst], make_float2(nr.d.y, nr.d.z));
+            qst(&out.state[dst], make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id)));
         }
         out_n += (uint32_t)__popcll(mask);
     }
@@ -1118,20 +1152,31 @@ __global__ __launch_bounds__(BLOCK) void k_queue_totals(DQueue q, uint32_t *tota
 // Single-wave workgroups and 16 loads in flight per thread keep a 1/8-frame tile share (32 Ki pixels = 512 waves for
 // 1024 SIMDs) near the HBM rate: 0.49 -> see DESIGN §7.
 __global__ __launch_bounds__(WB) void k_accumulate(DFrame f, const float4 *__restrict__ sample_rad, float4 *__restrict__ accum) {
+    // linear id of (sample s, pixel p) = s * n_pixels + p = (c * n_waves + w) * 64 + lane -> home = w * cap + c * 64 + lane;
+    // one sample further adds n_pixels = 64 * A + B to the linear id: (w, c, lane) are advanced without divisions
+    const uint32_t A = f.n_pixels >> 6, B = f.n_pixels & 63u, A_div = A / f.q_n_waves, A_mod = A % f.q_n_waves;
     for (uint32_t p = blockIdx.x * WB + threadIdx.x; p < f.n_pixels; p += gridDim.x * WB) {
         float4 a = accum[p];
-        const float4 *src = sample_rad + p;
+        uint32_t lane = p & 63u, c = (p >> 6) / f.q_n_waves, w = (p >> 6) % f.q_n_waves;
+        auto home_then_advance = [&]() {
+            const uint32_t home = (w << (f.q_shift + 6u)) | (c << 6) | lane;
+            lane += B;
+            const uint32_t carry = lane >> 6; lane &= 63u;
+            w += A_mod + carry; c += A_div;
+            if (w >= f.q_n_waves) { w -= f.q_n_waves; c++; }
+            return home;
+        };
         uint32_t s = 0;
         for (; s + 16u <= f.spp_batch; s += 16u) {
-            float4 c[16];
+            float4 v[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) c[k] = src[(size_t)(s + k) * f.n_pixels];
+            for (int k = 0; k < 16; k++) v[k] = sample_rad[home_then_advance()];
 #pragma unroll
-            for (int k = 0; k < 16; k++) { a.x += c[k].x; a.y += c[k].y; a.z += c[k].z; }   // render.rs:181: total_color += color(...)
+            for (int k = 0; k < 16; k++) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; }   // render.rs:181: total_color += color(...)
         }
         for (; s < f.spp_batch; s++) {
-            float4 c = src[(size_t)s * f.n_pixels];
-            a.x += c.x; a.y += c.y; a.z += c.z;
+            float4 v = sample_rad[home_then_advance()];
+            a.x += v.x; a.y += v.y; a.z += v.z;
         }
         accum[p] = a;
     }
@@ -1189,8 +1234,8 @@ void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mo
 // ------------------------------------------------------------------------------------------------
 static dim3 wave_grid(const LaunchCfg &c) { return dim3((c.q.n_waves + WB / 64 - 1) / (WB / 64)); }
 
-void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPaths out, uint32_t n_paths) {
-    hipLaunchKernelGGL(k_raygen, wave_grid(c), dim3(WB), 0, c.stream, cam, f, out, c.q, n_paths);
+void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPaths out, float4 *sample_rad, uint32_t n_paths) {
+    hipLaunchKernelGGL(k_raygen, wave_grid(c), dim3(WB), 0, c.stream, cam, f, out, sample_rad, c.q, n_paths);
 }
 void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float2 *hits, int segment, bool use_bvh) {
     int tl = use_bvh ? c.tlas_depth + 1 : 0;

@@ -681,7 +681,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         Workspace::Lane &L = ws->lanes[l];
         for (int k = 0; k < 2; k++) { need(L.ray_a[k], (size_t)cap * 16); need(L.ray_b[k], (size_t)cap * 8); need(L.state[k], (size_t)cap * 16); }
         need(L.hits, (size_t)cap * 8);
-        need(L.sample_rad, (size_t)max_paths * 16);
+        need(L.sample_rad, (size_t)cap * 16);                 // indexed by home slot
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
         if (!rc && !L.stream && n_lanes > 1) HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     }
@@ -715,6 +715,9 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     fr.width = p->width; fr.height = p->height; fr.n_pixels = n_pix; fr.inv_n_pixels = 1.0f / (float)n_pix; fr.inv_width = 1.0f / (float)p->width;
     fr.pixel_ids = p->pixel_ids ? (const uint32_t *)ws->pixel_ids.p : nullptr;
     fr.seed32 = (uint32_t)p->seed ^ ((uint32_t)(p->seed >> 32) * 0x9E3779B9u);
+    fr.q_n_waves = q.n_waves; fr.q_shift = q.cpw_shift;
+    const fw::DEnv &env = sc->d.env;
+    fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && getenv("FIREWORK_NO_ZERO_SKIP") == nullptr) ? 1u : 0u;
 
     // per-launch timing (FW_FLAG_TIME_KERNELS): one event after every launch on the launch's own stream; the end of
     // launch k is the start of launch k+1 of that lane.  With several lanes the intervals overlap in wall time.
@@ -759,7 +762,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         float2 *hits = (float2 *)L.hits.p;
         float4 *srad = (float4 *)L.sample_rad.p, *accum = (float4 *)ws->accum.p;
         int cur = 0;
-        timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], n_paths); });
+        timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], srad, n_paths); });
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
             if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
             else {

@@ -7,3 +7,5 @@ for rep in 1 2; do for f in $R/firework_amd/lib/variants/lib_*.so; do v=$(basena
 if [ -n "$AB_FULL" ]; then
 for f in $R/firework_amd/lib/variants/lib_*.so; do v=$(basename $f .so); FIREWORK_LIB=$f run $v "--config C3_suzanne --spp 64"; FIREWORK_LIB=$f run $v "--config C5_part2_all --spp 16"; FIREWORK_LIB=$f run $v "--config C4a_hdri_test --spp 128"; done
 fi
+if [ -n "$AB_NOLDS" ]; then FIREWORK_NO_LDS_TABLES=1 FIREWORK_LIB=$R/firework_amd/lib/variants/lib_base.so run base_nolds; fi
+if [ -n "$AB_TEST" ]; then timeout -k 10 300 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3; fi
