@@ -601,7 +601,7 @@ __device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint3
 // ------------------------------------------------------------------------------------------------
 extern __shared__ uint32_t lds_stack[];
 
-// Deferred mesh work (k_extend<true>): most rays of a chunk miss a mesh's box while a few walk its BLAS
+// Deferred mesh work (k_extend_bvh): most rays of a chunk miss a mesh's box while a few walk its BLAS
 // (rocprofv3 on suzanne: 14 % of lanes active).  A ray that reaches a mesh leaf of the TLAS does not enter the
 // BLAS; it parks (slot, mesh object, best hit so far) in a wave-private LDS list, and whenever 64 entries have
 // accumulated the whole wave walks BLASes together, one parked ray per lane, and writes the final hit records.
@@ -668,8 +668,8 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
 }
 
 template <bool USE_BVH>
-__global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits,
-                                                  DQueue q, int segment, int tlas_levels, int stack_levels) {
+__device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, const DPaths &in, float2 *__restrict__ hits,
+                                            const DQueue &q, int segment, int tlas_levels, int stack_levels) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     if (w >= q.n_waves) return;
     TS_BEGIN();
@@ -734,6 +734,18 @@ __global__ __launch_bounds__(WB) void k_extend(DScene sc, DFrame f, DPaths in, f
     }
     if (USE_BVH && list_n) flush(0u, list_n);
     TS_END();
+}
+// Two entry points because the register budget that pays differs.  The linear scan is VALU-issue-bound and its dependent
+// division chains want many waves: 7 per SIMD (72 VGPRs, no spills) 19.7 vs 20.2 ms at the compiler's own 73.  The BVH walk
+// waits on dependent node fetches: 5 waves (96 VGPRs, no spills) instead of 4 (104): suzanne 18.7 vs 20.6 ms, part2 14.9 vs
+// 16.2 ms at equal settings; 6 waves spill and lose again.
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(7, 8)))
+void k_extend_linear(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
+    extend_body<false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels);
+}
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(5, 8)))
+void k_extend_bvh(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
+    extend_body<true>(sc, f, in, hits, q, segment, tlas_levels, stack_levels);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1242,8 +1254,8 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     int levels = tl + c.blas_depth + 1;
     size_t lds = (size_t)levels * WB * sizeof(uint32_t) + (use_bvh && c.has_mesh ? 5 * DEFER_CAP * sizeof(uint32_t) : 0);
     dim3 eg = wave_grid(c);
-    if (use_bvh) hipLaunchKernelGGL(k_extend<true>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
-    else hipLaunchKernelGGL(k_extend<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+    if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+    else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment) {
