@@ -96,6 +96,8 @@ struct DFrame {
     float inv_n_pixels;           // 1.0f / n_pixels (path_id -> sample index without an integer division)
     uint32_t q_n_waves, q_shift;  // the batch's queue geometry (DQueue n_waves, cpw_shift): home slot <-> linear path id
     uint32_t skip_zero_deposits;  // black environment: k_raygen zeroes the deposits, k_shade writes only non-zero radiance
+    uint32_t pinhole0;            // aperture 0: every camera ray starts at cam_pos, segment-0 rays are stored as 16 B (direction only)
+    float cam_pos[3];
 };
 
 // ---- wavefront path state, SoA over path slots (DESIGN.md §"Path state")

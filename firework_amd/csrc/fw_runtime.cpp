@@ -716,6 +716,9 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     fr.pixel_ids = p->pixel_ids ? (const uint32_t *)ws->pixel_ids.p : nullptr;
     fr.seed32 = (uint32_t)p->seed ^ ((uint32_t)(p->seed >> 32) * 0x9E3779B9u);
     fr.q_n_waves = q.n_waves; fr.q_shift = q.cpw_shift;
+    fr.cam_pos[0] = cam.position[0]; fr.cam_pos[1] = cam.position[1]; fr.cam_pos[2] = cam.position[2];
+    fr.pinhole0 = (cam.lens_radius == 0.f && cam.position[0] != 0.f && cam.position[1] != 0.f && cam.position[2] != 0.f &&
+                   getenv("FIREWORK_NO_SHORT_RAYS") == nullptr) ? 1u : 0u;
     const fw::DEnv &env = sc->d.env;
     fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && getenv("FIREWORK_NO_ZERO_SKIP") == nullptr) ? 1u : 0u;
 
