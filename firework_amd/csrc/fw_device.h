@@ -22,6 +22,7 @@ enum : uint32_t {
     OF_RECT_FLIP = 1u << 2,    // AARect.flip_normal
     OF_MESH_NORMALS = 1u << 3, // TriangleMesh.normals is Some
     OF_MESH_ATTR = 1u << 4,    // the per-triangle attribute array (normals and/or v coordinates) is valid
+    OF_CULL0 = 1u << 6,        // expensive shape (Rect3d, mesh, cone, cylinder): camera-ray chunks test its inflated world box first
     OF_GATE = 1u << 5,         // the shape's own bounding box does not enclose it (Disk: disk.rs:85-90): under use_bvh the
                                // object is tested only if the ray hits the box of its leaf node in the REFERENCE tree
 };
@@ -70,6 +71,7 @@ struct DScene {
     const uint32_t *tri_rank; // in-order rank of each triangle in the REFERENCE tree of its mesh (tie-breaking)
     const uint32_t *obj_rank; // same for objects in the reference TLAS
     const float4 *obj_gate;   // per object: box (2 x float4) of its leaf node in the reference TLAS (used with OF_GATE)
+    const float4 *obj_cull;   // per object: enclosing world box (2 x float4) for the camera-ray pre-test of the linear scan
     const float4 *mat;
     const float4 *tex;
     const uint8_t *images;

@@ -452,6 +452,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         int32_t material = desc->shapes[o.shape].material;
         float *q = &objs[(size_t)i * fw::OBJ_Q * 4];
         const float pos[3] = {o.position.x, o.position.y, o.position.z};
+        if (kind == FW_SHAPE_RECT3D || kind == FW_SHAPE_TRIANGLE_MESH || kind == FW_SHAPE_CONE || kind == FW_SHAPE_CYLINDER) flags |= fw::OF_CULL0;
         q[0] = pos[0]; q[1] = pos[1]; q[2] = pos[2]; q[3] = bits_f(kind | (flags << 8) | (inner << 24));
         std::memcpy(q + 4, sp.q3, 16);
         std::memcpy(q + 8, sp.q4, 16);
@@ -488,6 +489,12 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
             // really enclose the geometry (so culling against the best t so far stays valid)
             if ((kf >> 8) & fw::OF_GATE) build_boxes[items[q]] = box_union(Box{{nd[0], nd[1], nd[2]}, {nd[4], nd[5], nd[6]}}, true_world[items[q]]);
         }
+    }
+    std::vector<float> cull((size_t)desc->n_objects * 8, 0.f);       // enclosing world boxes for the camera-ray pre-test (k_extend_linear)
+    for (uint32_t i = 0; i < desc->n_objects; i++) {
+        const Box &b = build_boxes[i];
+        float *c = &cull[(size_t)i * 8];
+        c[0] = b.mn.x; c[1] = b.mn.y; c[2] = b.mn.z; c[4] = b.mx.x; c[5] = b.mx.y; c[6] = b.mx.z;
     }
     if (use_sah()) { FlatBvh sah; sah_build(sah, build_boxes); tlas = std::move(sah); }
 
@@ -562,12 +569,13 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     // one device allocation + one copy for the whole scene (12 separate hipMalloc/hipFree pairs cost up to 30 ms of a
     // one-shot render): sections are 256-byte aligned inside a host staging blob
     struct Sec { const void *src; size_t bytes, off; };
-    Sec secs[12] = {
+    Sec secs[13] = {
         {objs.data(), objs.size() * 4, 0}, {tlas.nodes.data(), tlas.nodes.size() * 4, 0}, {fl.blas.nodes.data(), fl.blas.nodes.size() * 4, 0},
         {fl.tri.data(), fl.tri.size() * 4, 0}, {fl.any_attr ? fl.tri_attr.data() : nullptr, fl.any_attr ? fl.tri_attr.size() * 4 : 0, 0},
         {fl.tri_rank.data(), fl.tri_rank.size() * 4, 0}, {obj_rank.data(), obj_rank.size() * 4, 0}, {gate.data(), gate.size() * 4, 0},
         {mats.data(), mats.size() * 4, 0}, {texs.data(), texs.size() * 4, 0}, {images.data(), images.size(), 0},
-        {e.kind == FW_ENV_HDR ? e.hdr_rgb : nullptr, e.kind == FW_ENV_HDR ? (size_t)e.hdr_w * e.hdr_h * 3 * 4 : 0, 0}};
+        {e.kind == FW_ENV_HDR ? e.hdr_rgb : nullptr, e.kind == FW_ENV_HDR ? (size_t)e.hdr_w * e.hdr_h * 3 * 4 : 0, 0},
+        {cull.data(), cull.size() * 4, 0}};
     size_t total = 0;
     for (Sec &x : secs) { x.off = total; total += (x.bytes + 255) & ~(size_t)255; }
     total = std::max<size_t>(total, 256);
@@ -586,6 +594,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.tri_rank = (const uint32_t *)(base + secs[5].off); d.obj_rank = (const uint32_t *)(base + secs[6].off); d.obj_gate = (const float4 *)(base + secs[7].off);
     d.mat = (const float4 *)(base + secs[8].off); d.tex = (const float4 *)(base + secs[9].off); d.images = base + secs[10].off;
     const float *hdr_dev = (const float *)(base + secs[11].off);
+    d.obj_cull = (const float4 *)(base + secs[12].off);
     d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
     d.prim_bits = prim_bits;
     d.env.kind = e.kind;
