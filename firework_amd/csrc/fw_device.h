@@ -31,15 +31,22 @@ enum : uint32_t {
 //   cone / cylinder / disk : q3 = (radius height phi_max inner_radius)
 //   rect   : q3 = (a_min a_max b_min b_max)  q4.x = k
 //   rect3d : q3 = (pos.x pos.y pos.z size.x) q4 = (size.y size.z - -)
-//   mesh   : aux0 = BLAS root node index, aux1 = first triangle index
+//   mesh   : aux0 = BLAS root reference, aux1 = first triangle index
 //   medium : inner shape parameters in q3/q4 as above, q4.w = density, material = the Isotropic
 //            material, aux0/aux1 as for a mesh when the inner shape is one
 
-// ---- BVH node: 2 x float4 = 32 B.  DFS order: the left child of node i is i+1.
-//   lo = (min.xyz, bits A)   hi = (max.xyz, bits B)
-//   A>>30 == 0: Branch      right child = A & 0x3fffffff, B = split axis (depth % 3)
+// ---- BVH as walked on the device: PAIR NODES, 4 x float4 = 64 B, each holding the boxes of BOTH its children:
+//   (L.min.xyz, ref L) (L.max.xyz, ref R) (R.min.xyz, -) (R.max.xyz, -)
+//   a reference is the index of another pair node, or REF_LEAF | item (one object / one triangle per leaf), REF_DONE ends
+//   a walk.  One fetch decides two boxes (a node that carries only its own box makes every test wait for its own
+//   dependent fetch), and one item per leaf keeps the leaf phases uniform.  A tree of a single item has no node: its root
+//   reference is the leaf itself.
+// ---- BVH as built on the host (fw_runtime.cpp, FlatBvh: the reference's topology and the SAH tree before conversion):
+//   2 x float4 per node, DFS order (left child of node i is i+1):  lo = (min.xyz, bits A)   hi = (max.xyz, bits B)
+//   A>>30 == 0: Branch      right child = A & 0x3fffffff, B = split axis
 //   A>>30 == 1: Leaf        item = A & 0x3fffffff
 //   A>>30 == 2: DoubleLeaf  items = A & 0x3fffffff, B
+constexpr uint32_t REF_LEAF = 0x80000000u, REF_DONE = 0xffffffffu;
 constexpr uint32_t MF_NEEDS_UV = 1u << 8;    // the material's texture tree contains an ImageTexture
 constexpr uint32_t MF_TEX_CONST = 1u << 9;   // texture is a ConstantTexture, colour inlined in the record
 constexpr uint32_t NODE_LEAF = 1u, NODE_DOUBLE = 2u, NODE_MASK = 0x3fffffffu;
@@ -76,6 +83,7 @@ struct DScene {
     const float4 *tex;
     const uint8_t *images;
     uint32_t n_objects;
+    uint32_t tlas_root;       // root reference of the TLAS (a pair node, or REF_LEAF | object for a one-object scene)
     uint32_t has_medium;
     uint32_t has_mesh;
     uint32_t prim_bits;       // hit code = object << prim_bits | primitive

@@ -508,7 +508,17 @@ __device__ __forceinline__ bool hit_aabb(float4 lo, float4 hi, V3 o, V3 inv, flo
     tmin = fmaxf(tmin, inv.z < 0.f ? t1 : t0); tmax = fminf(tmax, inv.z < 0.f ? t0 : t1);
     return tmax > tmin;
 }
-
+// the same test, also returning where the ray enters the box (clamped to tmin): orders the two children of a pair node
+__device__ __forceinline__ bool hit_aabb_entry(float4 lo, float4 hi, V3 o, V3 inv, float tmin, float tmax, float &entry) {
+    float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
+    tmin = fmaxf(tmin, inv.x < 0.f ? t1 : t0); tmax = fminf(tmax, inv.x < 0.f ? t0 : t1);
+    t0 = (lo.y - o.y) * inv.y; t1 = (hi.y - o.y) * inv.y;
+    tmin = fmaxf(tmin, inv.y < 0.f ? t1 : t0); tmax = fminf(tmax, inv.y < 0.f ? t0 : t1);
+    t0 = (lo.z - o.z) * inv.z; t1 = (hi.z - o.z) * inv.z;
+    tmin = fmaxf(tmin, inv.z < 0.f ? t1 : t0); tmax = fminf(tmax, inv.z < 0.f ? t0 : t1);
+    entry = tmin;
+    return tmax > tmin;
+}
 // Per-lane traversal stack in LDS, laid out [level][lane] so a push/pop by the whole wave touches
 // 64 consecutive dwords (conflict-free).  `base` = first level this traversal may use.
 struct LdsStack {
@@ -516,6 +526,26 @@ struct LdsStack {
     __device__ __forceinline__ void push(uint32_t v) { s[sp * FW_WB] = v; sp++; }
     __device__ __forceinline__ uint32_t pop() { sp--; return s[sp * FW_WB]; }
 };
+
+// One step of a walk over PAIR NODES (fw_device.h: a node holds the boxes of BOTH its children, so one 64-byte fetch
+// decides two boxes; with one box per node every box test waited for its own dependent fetch and the walk was
+// latency-bound).  Returns the next reference: the nearer hit child (the farther one is pushed), else a popped one.
+__device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, uint32_t node, V3 o, V3 inv, float tmin, float cull,
+                                              LdsStack &st) {
+    const float4 *nd = nodes + 4 * (size_t)node;
+    const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+    float tl, tr;
+    const bool hl = hit_aabb_entry(q0, q1, o, inv, tmin, cull, tl), hr = hit_aabb_entry(q2, q3, o, inv, tmin, cull, tr);
+    const uint32_t rl = __float_as_uint(q0.w), rr = __float_as_uint(q1.w);
+    if (hl && hr) {
+        const bool left_first = tl <= tr;
+        st.push(left_first ? rr : rl);
+        return left_first ? rl : rr;
+    }
+    if (hl) return rl;
+    if (hr) return rr;
+    return st.sp ? st.pop() : REF_DONE;
+}
 
 // K4  mesh BLAS (bvh.rs:100-151 over Triangle items).  The reference visits BOTH children with the caller's
 // [tmin,tmax] and keeps the smaller t, the right/later item winning ties.  Here: front-to-back traversal
@@ -528,44 +558,27 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
                                          float tmax, float cull_t, uint32_t *stack_base, float &t_out, uint32_t &tri_out) {
     V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
     const TriRay tr = make_triray(r);
-    const uint32_t dir_neg = (r.d.x >= 0.f ? 0u : 1u) | (r.d.y >= 0.f ? 0u : 2u) | (r.d.z >= 0.f ? 0u : 4u);   // !(d >= 0): NaN counts as negative
     LdsStack st{stack_base, 0};
     bool have = false; float best = tmax; uint32_t best_tri = 0;
-    const uint32_t DONE = 0xffffffffu;
-    uint32_t node = root;
-    while (node != DONE) {
-        // while-while: every lane first walks inner nodes until it holds a leaf (or runs out of tree); only then
-        // do the lanes test triangles, together — the long triangle test is not run for one or two lanes at a time
-        uint32_t leafA = 0, leafB = 0; bool got_leaf = false;
-        while (node != DONE) {
+    uint32_t cur = root;                                                 // a reference: pair node, REF_LEAF | triangle, or REF_DONE
+    while (cur != REF_DONE) {
+        // while-while: every lane first walks pair nodes until it holds a leaf (or runs out of tree); only then do the
+        // lanes test triangles, together — the long triangle test is not run for one or two lanes at a time
+        while (!(cur & REF_LEAF)) {
             TS_TICK(4);
-            float4 lo = sc.blas[2 * (size_t)node], hi = sc.blas[2 * (size_t)node + 1];
             // cull_t: a t the caller already holds from another object (hits beyond it cannot win; equal t still can)
-            bool hit = hit_aabb(lo, hi, r.o, inv, tmin, have ? fminf(best, cull_t) : cull_t);
-            uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
-            if (hit && (A >> 30) == 0u) {
-                bool left_first = ((dir_neg >> (B & 3u)) & 1u) == 0u;
-                uint32_t left = node + 1, right = A & NODE_MASK;
-                st.push(left_first ? right : left);
-                node = left_first ? left : right;
-                continue;
-            }
-            node = st.sp ? st.pop() : DONE;
-            if (hit) { leafA = A; leafB = B; got_leaf = true; break; }
+            cur = pair_step(sc.blas, cur, r.o, inv, tmin, have ? fminf(best, cull_t) : cull_t, st);
         }
-        if (got_leaf) {
-            uint32_t items[2] = {leafA & NODE_MASK, leafB};
-            int n_items = ((leafA >> 30) == NODE_DOUBLE) ? 2 : 1;
-            for (int q = 0; q < n_items; q++) {
-                TS_TICK(6);
-                const float4 *tp = sc.tri + 3 * (size_t)(tri_base + items[q]);
-                float4 a = tp[0], b = tp[1], c = tp[2];
-                float t, b0, b1, b2;
-                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, tmin, tmax, t, b0, b1, b2)) {
-                    // tie -> the item that comes later in the reference tree's in-order (ranks fetched only then)
-                    if (!have || t < best || (t == best && sc.tri_rank[tri_base + items[q]] > sc.tri_rank[tri_base + best_tri])) { have = true; best = t; best_tri = items[q]; }
-                }
-            }
+        if (cur == REF_DONE) break;
+        const uint32_t item = cur & NODE_MASK;
+        cur = st.sp ? st.pop() : REF_DONE;
+        TS_TICK(6);
+        const float4 *tp = sc.tri + 3 * (size_t)(tri_base + item);
+        float4 a = tp[0], b = tp[1], c = tp[2];
+        float t, b0, b1, b2;
+        if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, tmin, tmax, t, b0, b1, b2)) {
+            // tie -> the item that comes later in the reference tree's in-order (ranks fetched only then)
+            if (!have || t < best || (t == best && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + best_tri])) { have = true; best = t; best_tri = item; }
         }
     }
     t_out = best; tri_out = best_tri;
@@ -668,45 +681,28 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
             if (hit_object(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
         }
     } else {
-        // bvh.rs:88-98,115-151 over RenderObjectInternal items; same front-to-back scheme as hit_mesh
+        // bvh.rs:88-98,115-151 over RenderObjectInternal items; same scheme as hit_mesh
         V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
-        const uint32_t dir_neg = (r.d.x >= 0.f ? 0u : 1u) | (r.d.y >= 0.f ? 0u : 2u) | (r.d.z >= 0.f ? 0u : 4u);
         LdsStack st{my_stack, 0};
         bool have = false;
-        const uint32_t DONE = 0xffffffffu;
-        uint32_t node = 0;
-        while (node != DONE) {
-            // while-while: walk inner nodes until this lane holds a leaf (or is out of tree); the lanes then
-            // run their object tests together (part2: 21 % of lanes were active in the interleaved form)
-            uint32_t leafA = 0, leafB = 0; bool got_leaf = false;
-            while (node != DONE) {
+        uint32_t cur = sc.tlas_root;
+        while (cur != REF_DONE) {
+            // while-while: walk pair nodes until this lane holds a leaf (or is out of tree); the lanes then run their
+            // object tests together (part2: 21 % of lanes were active in the interleaved form)
+            while (!(cur & REF_LEAF)) {
                 TS_TICK(0);
-                float4 lo = sc.tlas[2 * (size_t)node], hi = sc.tlas[2 * (size_t)node + 1];
-                bool hitb = hit_aabb(lo, hi, r.o, inv, TMIN, have ? best_t : TMAX);
-                uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
-                if (hitb && (A >> 30) == 0u) {
-                    bool left_first = ((dir_neg >> (B & 3u)) & 1u) == 0u;
-                    uint32_t left = node + 1, right = A & NODE_MASK;
-                    st.push(left_first ? right : left);
-                    node = left_first ? left : right;
-                    continue;
-                }
-                node = st.sp ? st.pop() : DONE;
-                if (hitb) { leafA = A; leafB = B; got_leaf = true; break; }
+                cur = pair_step(sc.tlas, cur, r.o, inv, TMIN, have ? best_t : TMAX, st);
             }
-            if (got_leaf) {
-                uint32_t items[2] = {leafA & NODE_MASK, leafB};
-                int n_items = ((leafA >> 30) == NODE_DOUBLE) ? 2 : 1;
-                for (int qq = 0; qq < n_items; qq++) {
-                    Obj o = load_obj_for_hit(sc.obj, items[qq]);
-                    if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)items[qq]], sc.obj_gate[2 * (size_t)items[qq] + 1], r.o, inv, TMIN, TMAX)) continue;
-                    if (DEFER && sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = items[qq]; continue; }   // park the first mesh
-                    TS_TICK(2);
-                    float t; uint32_t prim;
-                    if (hit_object(sc, o, items[qq], r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
-                        if (!have || t < best_t || (t == best_t && sc.obj_rank[items[qq]] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = items[qq]; best_prim = prim; }
-                    }
-                }
+            if (cur == REF_DONE) break;
+            const uint32_t item = cur & NODE_MASK;
+            cur = st.sp ? st.pop() : REF_DONE;
+            Obj o = load_obj_for_hit(sc.obj, item);
+            if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)item], sc.obj_gate[2 * (size_t)item + 1], r.o, inv, TMIN, TMAX)) continue;
+            if (DEFER && sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = item; continue; }   // park the first mesh
+            TS_TICK(2);
+            float t; uint32_t prim;
+            if (hit_object(sc, o, item, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+                if (!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = item; best_prim = prim; }
             }
         }
     }

@@ -199,6 +199,49 @@ void sah_build(FlatBvh &out, const std::vector<Box> &boxes) {
     Box root;
     sah_build_rec(out, boxes, idx.data(), idx.size(), 0, root);
 }
+
+// ---- the tree as walked on the device: pair nodes (fw_device.h), converted from a FlatBvh.  A DoubleLeaf becomes a
+// pair node over two single-item leaves, each with its own box.  `depth` = inner nodes on the longest root-to-leaf path
+// = the most references a walk can have pushed.
+struct PairBvh {
+    std::vector<float> nodes;   // 16 floats per pair node
+    uint32_t depth = 0;
+    uint32_t count() const { return (uint32_t)(nodes.size() / 16); }
+};
+static uint32_t pair_convert_rec(const FlatBvh &src, uint32_t i, const std::vector<Box> &item_boxes, PairBvh &out, uint32_t base,
+                                 uint32_t depth, Box &box) {
+    const float *nd = &src.nodes[(size_t)i * 8];
+    uint32_t A, B; std::memcpy(&A, nd + 3, 4); std::memcpy(&B, nd + 7, 4);
+    box = Box{{nd[0], nd[1], nd[2]}, {nd[4], nd[5], nd[6]}};
+    const uint32_t kind = A >> 30;
+    if (kind == fw::NODE_LEAF) return fw::REF_LEAF | (A & fw::NODE_MASK);
+    const uint32_t me = out.count();
+    out.nodes.resize(out.nodes.size() + 16, 0.f);
+    out.depth = std::max(out.depth, depth + 1);
+    uint32_t rl, rr; Box bl, br;
+    if (kind == fw::NODE_DOUBLE) {
+        rl = fw::REF_LEAF | (A & fw::NODE_MASK); bl = item_boxes[A & fw::NODE_MASK];
+        rr = fw::REF_LEAF | B; br = item_boxes[B];
+    } else {
+        rl = pair_convert_rec(src, i + 1, item_boxes, out, base, depth + 1, bl);
+        rr = pair_convert_rec(src, A & fw::NODE_MASK, item_boxes, out, base, depth + 1, br);
+    }
+    float *p = &out.nodes[(size_t)me * 16];
+    p[0] = bl.mn.x; p[1] = bl.mn.y; p[2] = bl.mn.z; p[3] = bits_f(rl);
+    p[4] = bl.mx.x; p[5] = bl.mx.y; p[6] = bl.mx.z; p[7] = bits_f(rr);
+    p[8] = br.mn.x; p[9] = br.mn.y; p[10] = br.mn.z; p[12] = br.mx.x; p[13] = br.mx.y; p[14] = br.mx.z;
+    return base + me;
+}
+// appends the converted tree to `out` (whose nodes already hold `base` = out.count() pair nodes of other trees) and returns its root reference
+static uint32_t pair_convert(const FlatBvh &src, const std::vector<Box> &item_boxes, PairBvh &out) {
+    Box root;
+    PairBvh local;
+    uint32_t base = out.count();
+    uint32_t ref = pair_convert_rec(src, 0, item_boxes, local, base, 0, root);
+    out.nodes.insert(out.nodes.end(), local.nodes.begin(), local.nodes.end());
+    out.depth = std::max(out.depth, local.depth);
+    return ref;
+}
 inline bool use_sah() { const char *e = getenv("FIREWORK_BVH"); return !(e && std::strcmp(e, "median") == 0); }
 
 // ---- device allocations owned by a scene / workspace ----------------------------------------------------
@@ -286,7 +329,7 @@ struct Flattener {
     std::vector<float> tri, tri_attr;     // 12 floats per triangle each
     std::vector<uint32_t> tri_rank;       // in-order rank of each triangle in the reference tree of its mesh
     bool any_attr = false;
-    FlatBvh blas;
+    PairBvh blas;                 // all meshes' trees, as walked on the device
     uint32_t blas_depth = 0, ref_blas_nodes = 0, max_tris = 0;
 
     int check_material(int32_t m) const { return (m < 0 || (uint32_t)m >= d->n_materials) ? FW_ERR_BAD_ARG : FW_OK; }
@@ -383,14 +426,8 @@ struct Flattener {
         }
         ref_blas_nodes += local.count();
         if (use_sah()) { FlatBvh sah; sah_build(sah, boxes); local = std::move(sah); }
-        uint32_t root = blas.count();
-        // rebase child links of the local tree into the shared BLAS array
-        for (uint32_t i = 0; i < local.count(); i++) {
-            uint32_t A; std::memcpy(&A, &local.nodes[(size_t)i * 8 + 3], 4);
-            if ((A >> 30) == 0) { A += root; local.nodes[(size_t)i * 8 + 3] = bits_f(A); }
-        }
-        blas.nodes.insert(blas.nodes.end(), local.nodes.begin(), local.nodes.end());
-        blas_depth = std::max(blas_depth, local.depth);
+        uint32_t root = pair_convert(local, boxes, blas);     // root reference into the shared BLAS array
+        blas_depth = blas.depth;
         sp.aux0 = root; sp.aux1 = tri_base;
         if (s.normals) sp.flags |= fw::OF_MESH_NORMALS;
         if (attr) sp.flags |= fw::OF_MESH_ATTR;
@@ -497,6 +534,8 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         c[0] = b.mn.x; c[1] = b.mn.y; c[2] = b.mn.z; c[4] = b.mx.x; c[5] = b.mx.y; c[6] = b.mx.z;
     }
     if (use_sah()) { FlatBvh sah; sah_build(sah, build_boxes); tlas = std::move(sah); }
+    PairBvh tlas_p;
+    const uint32_t tlas_root = pair_convert(tlas, build_boxes, tlas_p);
 
     // materials / textures / images
     std::vector<float> mats((size_t)std::max(1u, desc->n_materials) * 8, 0.f), texs((size_t)std::max(1u, desc->n_textures) * 8, 0.f);
@@ -559,7 +598,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     if (e.kind == FW_ENV_HDR && (!e.hdr_rgb || !e.hdr_w || !e.hdr_h)) return fail(FW_ERR_BAD_ARG, "HdrEnv without pixels");
 
     // stack depth the kernels will be given
-    if (tlas.depth + 1 + fl.blas_depth + 1 > 120) return fail(FW_ERR_BVH_DEPTH, "BVH deeper than the LDS traversal stack (120 levels)");
+    if (tlas_p.depth + 1 + fl.blas_depth + 1 > 120) return fail(FW_ERR_BVH_DEPTH, "BVH deeper than the LDS traversal stack (120 levels)");
 
     fw_scene *sc = new (std::nothrow) fw_scene();
     if (!sc) return fail(FW_ERR_OOM, "host allocation failed");
@@ -570,7 +609,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     // one-shot render): sections are 256-byte aligned inside a host staging blob
     struct Sec { const void *src; size_t bytes, off; };
     Sec secs[13] = {
-        {objs.data(), objs.size() * 4, 0}, {tlas.nodes.data(), tlas.nodes.size() * 4, 0}, {fl.blas.nodes.data(), fl.blas.nodes.size() * 4, 0},
+        {objs.data(), objs.size() * 4, 0}, {tlas_p.nodes.data(), tlas_p.nodes.size() * 4, 0}, {fl.blas.nodes.data(), fl.blas.nodes.size() * 4, 0},
         {fl.tri.data(), fl.tri.size() * 4, 0}, {fl.any_attr ? fl.tri_attr.data() : nullptr, fl.any_attr ? fl.tri_attr.size() * 4 : 0, 0},
         {fl.tri_rank.data(), fl.tri_rank.size() * 4, 0}, {obj_rank.data(), obj_rank.size() * 4, 0}, {gate.data(), gate.size() * 4, 0},
         {mats.data(), mats.size() * 4, 0}, {texs.data(), texs.size() * 4, 0}, {images.data(), images.size(), 0},
@@ -596,7 +635,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     const float *hdr_dev = (const float *)(base + secs[11].off);
     d.obj_cull = (const float4 *)(base + secs[12].off);
     d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
-    d.prim_bits = prim_bits;
+    d.prim_bits = prim_bits; d.tlas_root = tlas_root;
     d.env.kind = e.kind;
     d.env.color[0] = e.color.x; d.env.color[1] = e.color.y; d.env.color[2] = e.color.z;
     d.env.zenith[0] = e.zenith.x; d.env.zenith[1] = e.zenith.y; d.env.zenith[2] = e.zenith.z;
@@ -604,7 +643,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.env.hdr = hdr_dev; d.env.hdr_w = e.hdr_w; d.env.hdr_h = e.hdr_h;
     sc->hdr_env = e.kind == FW_ENV_HDR;
     sc->tlas_nodes = ref_tlas_nodes; sc->blas_nodes = fl.ref_blas_nodes;   // reported: the reference topology (bvh.rs)
-    sc->tlas_depth = tlas.depth; sc->blas_depth = fl.blas_depth;
+    sc->tlas_depth = tlas_p.depth; sc->blas_depth = fl.blas_depth;
     sc->n_mat = desc->n_materials; sc->n_tex = desc->n_textures;
     *out = sc;
     return FW_OK;
