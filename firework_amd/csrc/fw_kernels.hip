@@ -530,12 +530,17 @@ struct LdsStack {
 // One step of a walk over PAIR NODES (fw_device.h: a node holds the boxes of BOTH its children, so one 64-byte fetch
 // decides two boxes; with one box per node every box test waited for its own dependent fetch and the walk was
 // latency-bound).  Returns the next reference: the nearer hit child (the farther one is pushed), else a popped one.
-__device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, uint32_t node, V3 o, V3 inv, float tmin, float cull,
-                                              LdsStack &st) {
+// A child is entered when the reference's own test passes (aabb.rs:30-50 with the caller's [tmin, tmax]) and its entry
+// is not clearly beyond the best hit so far: `cull` = cull_bound(best t) = best t + 1e-6 |best t|.  The slack covers the few ulp by which a
+// computed slab entry can exceed the t of a hit lying on the box face, and keeps exact ties (which the in-order rank
+// decides) reachable — so the result does not depend on the shape of the walked tree.
+__device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, uint32_t node, V3 o, V3 inv, float tmin, float tmax,
+                                              float cull, LdsStack &st) {
     const float4 *nd = nodes + 4 * (size_t)node;
     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
     float tl, tr;
-    const bool hl = hit_aabb_entry(q0, q1, o, inv, tmin, cull, tl), hr = hit_aabb_entry(q2, q3, o, inv, tmin, cull, tr);
+    bool hl = hit_aabb_entry(q0, q1, o, inv, tmin, tmax, tl), hr = hit_aabb_entry(q2, q3, o, inv, tmin, tmax, tr);
+    hl = hl && !(tl > cull); hr = hr && !(tr > cull);
     const uint32_t rl = __float_as_uint(q0.w), rr = __float_as_uint(q1.w);
     if (hl && hr) {
         const bool left_first = tl <= tr;
@@ -546,6 +551,8 @@ __device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, 
     if (hr) return rr;
     return st.sp ? st.pop() : REF_DONE;
 }
+// best t -> culling bound, a little beyond it whatever its sign (a medium's inner mesh is walked with t in (-MAX, MAX))
+__device__ __forceinline__ float cull_bound(float t) { return t + fabsf(t) * 1e-6f; }
 
 // K4  mesh BLAS (bvh.rs:100-151 over Triangle items).  The reference visits BOTH children with the caller's
 // [tmin,tmax] and keeps the smaller t, the right/later item winning ties.  Here: front-to-back traversal
@@ -567,7 +574,7 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
         while (!(cur & REF_LEAF)) {
             TS_TICK(4);
             // cull_t: a t the caller already holds from another object (hits beyond it cannot win; equal t still can)
-            cur = pair_step(sc.blas, cur, r.o, inv, tmin, have ? fminf(best, cull_t) : cull_t, st);
+            cur = pair_step(sc.blas, cur, r.o, inv, tmin, tmax, cull_bound(have ? fminf(best, cull_t) : cull_t), st);
         }
         if (cur == REF_DONE) break;
         const uint32_t item = cur & NODE_MASK;
@@ -691,7 +698,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
             // object tests together (part2: 21 % of lanes were active in the interleaved form)
             while (!(cur & REF_LEAF)) {
                 TS_TICK(0);
-                cur = pair_step(sc.tlas, cur, r.o, inv, TMIN, have ? best_t : TMAX, st);
+                cur = pair_step(sc.tlas, cur, r.o, inv, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
             }
             if (cur == REF_DONE) break;
             const uint32_t item = cur & NODE_MASK;

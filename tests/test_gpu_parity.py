@@ -187,6 +187,21 @@ def test_batching_and_pixel_subsets_are_bit_identical(oracle):
     assert np.array_equal(out, full.linear)
 
 
+def test_image_does_not_depend_on_the_walked_tree(monkeypatch):
+    """Hits are ordered by (t, in-order rank of the REFERENCE tree) and boxes are culled conservatively, so walking the
+    binned-SAH tree (default) or the reference's median-split topology (FIREWORK_BVH=median) gives the same bits and the
+    same ray counts — at sizes where exact ties and hits on box faces do occur (part2's floor of abutting boxes)."""
+    for name, w, h, spp in (("C5_part2_all", 320, 180, 8), ("C3_suzanne", 160, 90, 16), ("C1_random_spheres", 200, 112, 16)):
+        s, r = scenes.config(name, w, h, spp)
+        monkeypatch.delenv("FIREWORK_BVH", raising=False)
+        sah = r.render_full(s)
+        monkeypatch.setenv("FIREWORK_BVH", "median")
+        med = r.render_full(s)
+        monkeypatch.delenv("FIREWORK_BVH", raising=False)
+        assert sah.stats["rays"] == med.stats["rays"], name
+        assert np.array_equal(sah.linear, med.linear), name
+
+
 def test_fused_bounce_kernel_is_bit_identical_to_the_split_kernels(monkeypatch):
     """FIREWORK_FUSED=1 intersects and shades in one launch per segment (k_bounce) with the device functions of
     k_extend / k_shade: same bits, same ray counts, linear scan and TLAS."""
