@@ -646,7 +646,27 @@ extern __shared__ uint32_t lds_stack[];
 // (rocprofv3 on suzanne: 14 % of lanes active).  A ray that reaches a mesh leaf of the TLAS does not enter the
 // BLAS; it parks (slot, mesh object, best hit so far) in a wave-private LDS list, and whenever 64 entries have
 // accumulated the whole wave walks BLASes together, one parked ray per lane, and writes the final hit records.
-constexpr uint32_t DEFER_CAP = 128;   // entries; a chunk adds at most 64, a flush removes 64
+#ifndef FW_BLAS_RUN_MIN
+#define FW_BLAS_RUN_MIN 128
+#endif
+#ifndef FW_BLAS_REFILL_MIN
+#define FW_BLAS_REFILL_MIN 16
+#endif
+constexpr uint32_t DEFER_CAP = FW_BLAS_RUN_MIN + 64;        // entries; a chunk adds at most 64 and the list is emptied when it reaches BLAS_RUN_MIN
+constexpr uint32_t BLAS_RUN_MIN = FW_BLAS_RUN_MIN;     // parked rays that start a BLAS run (the more, the smaller the share of its tail)
+constexpr uint32_t BLAS_REFILL_MIN = FW_BLAS_REFILL_MIN;   // idle lanes that trigger a refill inside a run
+#ifndef FW_BLAS_WALK_NUM
+#define FW_BLAS_WALK_NUM 2
+#define FW_BLAS_WALK_DEN 1
+#endif
+#ifndef FW_WALK_NUM
+#define FW_WALK_NUM 4
+#define FW_WALK_DEN 1
+#endif
+static_assert(FW_WALK_NUM > FW_WALK_DEN, "the walk must continue while every busy lane walks");
+constexpr uint32_t WALK_NUM = FW_WALK_NUM, WALK_DEN = FW_WALK_DEN;   // same rule for the TLAS walk
+static_assert(FW_BLAS_WALK_NUM > FW_BLAS_WALK_DEN, "the walk must continue while every busy lane walks");
+constexpr uint32_t BLAS_WALK_NUM = FW_BLAS_WALK_NUM, BLAS_WALK_DEN = FW_BLAS_WALK_DEN;   // node walking stops when walkers * NUM <= busy lanes * DEN
 static_assert(FW_WB == 64, "the parked-ray list and the wave-private queues assume single-wave workgroups");
 
 // Closest hit of one ray: the linear scan of scene.rs:137-149 or the TLAS walk of bvh.rs:115-151.  With DEFER a
@@ -693,14 +713,25 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
         LdsStack st{my_stack, 0};
         bool have = false;
         uint32_t cur = sc.tlas_root;
-        while (cur != REF_DONE) {
-            // while-while: walk pair nodes until this lane holds a leaf (or is out of tree); the lanes then run their
-            // object tests together (part2: 21 % of lanes were active in the interleaved form)
-            while (!(cur & REF_LEAF)) {
-                TS_TICK(0);
-                cur = pair_step(sc.tlas, cur, r.o, inv, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
+        // Rounds of (node steps, then object tests).  A lane walks pair nodes until it holds a leaf or is out of tree; the
+        // WAVE stops walking once no more than a quarter of its busy lanes still walk, so that most lanes test their object now
+        // instead of waiting for the stragglers, who go on in the next round (suzanne BLAS: 15.2 -> 12.2 ms with the same
+        // rule; the plain while-while ran the node loop at 30 % lane utilisation).  All lanes that entered call this
+        // together: the ballots see exactly them.
+        for (;;) {
+            const bool busy = cur != REF_DONE;
+            const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
+            if (n_busy == 0u) break;
+            for (;;) {
+                const bool walking = busy && !(cur & REF_LEAF);
+                const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+                if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;   // n_walk < n_busy: somebody holds a leaf or has finished
+                if (walking) {
+                    TS_TICK(0);
+                    cur = pair_step(sc.tlas, cur, r.o, inv, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
+                }
             }
-            if (cur == REF_DONE) break;
+            if (!busy || !(cur & REF_LEAF) || cur == REF_DONE) continue;
             const uint32_t item = cur & NODE_MASK;
             cur = st.sp ? st.pop() : REF_DONE;
             Obj o = load_obj_for_hit(sc.obj, item);
@@ -732,20 +763,70 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
     uint32_t list_n = 0;
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
 
-    auto flush = [&](uint32_t first, uint32_t count) {               // entries [first, first+count), count <= 64
-        if (lane < count) {
-            const uint32_t e = first + lane;
-            const uint32_t slot = e_slot[e], obj = e_obj[e];
-            float bt = e_t[e]; uint32_t bobj = e_bobj[e], bprim = e_bprim[e];
-            float4 ra = qld(&in.ray_a[slot]); float2 rb = load_ray_b(in, slot, f, segment);
-            Ray world = make_ray(ra, rb, f, segment);
-            Obj o = load_obj(sc.obj, obj);
-            Ray r = to_object_space(o, world);
-            float t; uint32_t prim;
-            if (hit_mesh(sc, o.aux0, o.aux1, r, TMIN, TMAX, bt, blas_stack, t, prim)) {
-                if (bobj == MISS || t < bt || (t == bt && sc.obj_rank[obj] > sc.obj_rank[bobj])) { bt = t; bobj = obj; bprim = prim; }
+    // Walks the BLASes of ALL parked rays.  64 rays start together; a lane that finishes its ray writes the hit record and,
+    // once BLAS_REFILL_MIN lanes are idle, the idle lanes take further parked rays (from the end of the LDS list), so the
+    // few deep walks of a batch overlap with many short ones instead of holding 63 idle lanes (suzanne: the node loop ran
+    // at 14 % lane utilisation, tools/trav_stats.py).  Same arithmetic and tie rules as hit_mesh + the merge of the old
+    // one-shot flush; the order in which parked rays are walked does not matter (each writes its own slot).
+    auto blas_run = [&]() {
+        bool act = false, have = false;
+        uint32_t slot = 0, obj = 0, tri_base = 0, bobj = MISS, bprim = 0, mtri = 0, cur = REF_DONE;
+        float bt = TMAX, mbest = TMAX;
+        V3 ro = mk(0, 0, 0), inv = ro;
+        TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
+        LdsStack st{blas_stack, 0};
+        for (;;) {
+            const unsigned long long idle_mask = __ballot(!act);
+            const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+            if (list_n > 0u && n_idle >= BLAS_REFILL_MIN) {
+                const uint32_t take = min(n_idle, list_n);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                if (!act && rank < take) {
+                    const uint32_t e = list_n - 1u - rank;
+                    slot = e_slot[e]; obj = e_obj[e]; bt = e_t[e]; bobj = e_bobj[e]; bprim = e_bprim[e];
+                    float4 ra = qld(&in.ray_a[slot]); float2 rb = load_ray_b(in, slot, f, segment);
+                    Obj o = load_obj(sc.obj, obj);
+                    Ray r = to_object_space(o, make_ray(ra, rb, f, segment));
+                    ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                    tr = make_triray(r);
+                    tri_base = o.aux1; cur = o.aux0; st.sp = 0;
+                    have = false; mbest = TMAX; mtri = 0; act = true;
+                }
+                list_n -= take;
             }
-            qst(&hits[slot], pack_hit(bt, bobj, bprim, sc.prim_bits));
+            const uint32_t n_idle_after = (uint32_t)__popcll(__ballot(!act));
+            if (n_idle_after == 64u) break;                            // the list is empty too: 64 idle lanes would have refilled
+            // walk pair nodes until this lane holds a triangle (or is out of tree) — but the WAVE stops walking as soon as
+            // no more than a quarter of its busy lanes still walk: the rest test their triangles now instead of waiting
+            // for the stragglers, who simply go on in the next round
+            const uint32_t n_act = 64u - n_idle_after;
+            for (;;) {
+                const bool walking = act && !(cur & REF_LEAF);
+                const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+                if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;   // n_walk < n_act: somebody holds a leaf, the round makes progress
+                if (walking) {
+                    TS_TICK(4);
+                    cur = pair_step(sc.blas, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
+                }
+            }
+            if (act && (cur & REF_LEAF)) {
+                if (cur != REF_DONE) {
+                    const uint32_t item = cur & NODE_MASK;
+                    cur = st.sp ? st.pop() : REF_DONE;
+                    TS_TICK(6);
+                    const float4 *tp = sc.tri + 3 * (size_t)(tri_base + item);
+                    float4 a = tp[0], b = tp[1], c = tp[2];
+                    float t, b0, b1, b2;
+                    if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, TMIN, TMAX, t, b0, b1, b2)) {
+                        if (!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) { have = true; mbest = t; mtri = item; }
+                    }
+                }
+                if (cur == REF_DONE) {                                  // this ray is finished: merge with what the TLAS walk held
+                    if (have && (bobj == MISS || mbest < bt || (mbest == bt && sc.obj_rank[obj] > sc.obj_rank[bobj]))) { bt = mbest; bobj = obj; bprim = mtri; }
+                    qst(&hits[slot], pack_hit(bt, bobj, bprim, sc.prim_bits));
+                    act = false;
+                }
+            }
         }
     };
 
@@ -776,11 +857,11 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                     e_slot[e] = i; e_obj[e] = deferred_obj; e_t[e] = best_t; e_bobj[e] = best_obj; e_bprim[e] = best_prim;
                 }
                 list_n += (uint32_t)__popcll(mask);
-                if (list_n >= 64u) { list_n -= 64u; flush(list_n, 64u); }
+                if (list_n >= BLAS_RUN_MIN) blas_run();
             }
         }
     }
-    if (USE_BVH && list_n) flush(0u, list_n);
+    if (USE_BVH && list_n) blas_run();
     TS_END();
 }
 // Two entry points because the register budget that pays differs.  The linear scan is VALU-issue-bound and its dependent
