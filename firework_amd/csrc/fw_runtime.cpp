@@ -711,7 +711,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
 
     // wave-private queues: many more waves than are resident, each owning >= 8 chunks of 64 paths when the batch allows
     fw::DQueue q;
-    uint32_t want_waves = (uint32_t)sc->n_cus * 512u;
+    // How many: whole rounds of resident waves for BOTH queue kernels (k_extend_linear holds 7 waves per SIMD, k_extend_bvh 5,
+    // k_shade 4 -> multiples of lcm x SIMDs), and 16-50 chunks per wave so that the half-empty last chunk of a queue stays
+    // small; measured on cornell (tools/waves_sweep.sh): whole frame 86 016 waves 41.1 ms vs 131 072: 42.0; the 1/4 share of
+    // a 4-GPU frame 57 344: 12.7 vs 13.7 ms; the 1/8 share 28 672: 6.30 vs 6.67 ms.
+    const uint32_t unit = (uint32_t)sc->n_cus * 4u * (p->use_bvh ? 20u : 28u);
+    const uint64_t chunks = ((uint64_t)max_paths + 63u) / 64u;
+    uint32_t want_waves = unit * (uint32_t)std::min<uint64_t>(3u, std::max<uint64_t>(1u, chunks / ((uint64_t)unit * 16u)));
     if (const char *e = getenv("FIREWORK_WAVES")) { long v = atol(e); if (v > 0) want_waves = (uint32_t)v; }
     q.n_waves = std::max(4u, std::min(want_waves, (max_paths + 511u) / 512u));
     q.n_waves = (q.n_waves + 3u) & ~3u;
