@@ -343,42 +343,60 @@ __device__ __forceinline__ bool hit_sphere(float radius, const Ray &r, float tmi
 }
 
 // objects/rect.rs:47-73.  AX: 0 = XY (plane axis z), 1 = XZ (plane axis y), 2 = YZ (plane axis x)
-template <int AX>
+template <int AX, bool DEGENERATE>
 __device__ __forceinline__ bool hit_rect(float a_min, float a_max, float b_min, float b_max, float k, const Ray &r,
                                          float tmin, float tmax, float &t_out) {
     constexpr int A1 = (AX == 2) ? 1 : 0, A2 = (AX == 0) ? 1 : 2, OT = (AX == 0) ? 2 : (AX == 1 ? 1 : 0);
-    // rect.rs:47-62 as ONE comparison: the six range tests `x < lo || x > hi` are signs of exact differences
-    // (x - lo < 0 iff x < lo in IEEE arithmetic with denormals), so the hit is `min of the six slacks >= 0`.
-    // fminf drops NaNs just as the reference's comparisons are all false on them.  Why: 18 of these run per
-    // cornell ray, and six v_cmp + five s_or_b64 each kept the CU's single scalar unit ~80 % busy (rocprofv3:
-    // 466 SALU vs 603 VALU instructions per wave-chunk); min3 chains stay on the vector pipes.
+    // rect.rs:47-62: three interval tests, each rejecting on `x < lo || x > hi` (so a NaN passes, as in the reference).
+    // 18 of these run per cornell ray and the kernel is VALU-issue-bound, so the form matters:
+    //   x in [lo, hi]  <=>  x == med3(x, lo, hi)   when lo <= hi:  v_med3 + one compare per interval, "not (less or
+    //   greater)" so that a NaN x still passes (med3 returns a non-NaN bound then) — 18.8 vs 19.7 ms against the previous form,
+    //   min of the six differences (x - lo, hi - x, ...) >= 0 with NaN-dropping fminf, which is kept for DEGENERATE rects
+    //   (lo > hi on some interval, flagged by the host: nothing passes there, but a median would).
+    // Six v_cmp + five s_or_b64 per rect (the literal form) kept the scalar unit ~80 % busy in the first version.
     float t = fdiv(k - comp(r.o, OT), comp(r.d, OT));
     float pa = comp(r.o, A1) + t * comp(r.d, A1), pb = comp(r.o, A2) + t * comp(r.d, A2);
-    float slack = fminf(fminf(fminf(t - tmin, tmax - t), fminf(pa - a_min, a_max - pa)), fminf(pb - b_min, b_max - pb));
     t_out = t;
-    return !(slack < 0.f);
+    if (DEGENERATE) {
+        float slack = fminf(fminf(fminf(t - tmin, tmax - t), fminf(pa - a_min, a_max - pa)), fminf(pb - b_min, b_max - pb));
+        return !(slack < 0.f);
+    }
+    const float mt = __builtin_amdgcn_fmed3f(t, tmin, tmax), ma = __builtin_amdgcn_fmed3f(pa, a_min, a_max), mb = __builtin_amdgcn_fmed3f(pb, b_min, b_max);
+    return !(t < mt || t > mt) && !(pa < ma || pa > ma) && !(pb < mb || pb > mb);
 }
-__device__ __forceinline__ bool hit_rect_kind(uint32_t kind, float4 q3, float k, const Ray &r, float tmin, float tmax, float &t) {
-    if (kind == 1) return hit_rect<0>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
-    if (kind == 2) return hit_rect<1>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
-    return hit_rect<2>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
+template <bool DEGENERATE>
+__device__ __forceinline__ bool hit_rect_kind_t(uint32_t kind, float4 q3, float k, const Ray &r, float tmin, float tmax, float &t) {
+    if (kind == 1) return hit_rect<0, DEGENERATE>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
+    if (kind == 2) return hit_rect<1, DEGENERATE>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
+    return hit_rect<2, DEGENERATE>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
+}
+// q4 = (k, degenerate flag, -, -)
+__device__ __forceinline__ bool hit_rect_kind(uint32_t kind, float4 q3, float4 q4, const Ray &r, float tmin, float tmax, float &t) {
+    if (q4.y != 0.f) return hit_rect_kind_t<true>(kind, q3, q4.x, r, tmin, tmax, t);
+    return hit_rect_kind_t<false>(kind, q3, q4.x, r, tmin, tmax, t);
 }
 
 // objects/rect3d.rs:18-100 — faces +z, -z, +y, -y, +x, -x; linear closest with narrowing, later wins ties.
 // (Measured and rejected: the two parallel faces of an axis as one packed-f32 computation — v_pk_fma/mul/add issue at half
 // the rate of their scalar forms on gfx950, tools/microbench.hip, so nothing is gained and the repacking costs: 28.0 vs 24.3 ms.)
-__device__ __forceinline__ bool hit_rect3d(float4 q3, float4 q4, const Ray &r, float tmin, float tmax, float &t_out, uint32_t &face) {
+template <bool DEGENERATE>
+__device__ __forceinline__ bool hit_rect3d_t(float4 q3, float4 q4, const Ray &r, float tmin, float tmax, float &t_out, uint32_t &face) {
     float px = q3.x, py = q3.y, pz = q3.z, sx = q3.w, sy = q4.x, sz = q4.y;
     bool any = false; float closest = tmax, t; face = 0;
     bool h;   // predicated: no exec-mask bookkeeping between the six faces
-    h = hit_rect<0>(px, px + sx, py, py + sy, pz + sz, r, tmin, closest, t); closest = h ? t : closest; face = h ? 0u : face; any |= h;
-    h = hit_rect<0>(px, px + sx, py, py + sy, pz, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 1u : face; any |= h;
-    h = hit_rect<1>(px, px + sx, pz, pz + sz, py + sy, r, tmin, closest, t); closest = h ? t : closest; face = h ? 2u : face; any |= h;
-    h = hit_rect<1>(px, px + sx, pz, pz + sz, py, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 3u : face; any |= h;
-    h = hit_rect<2>(py, py + sy, pz, pz + sz, px + sx, r, tmin, closest, t); closest = h ? t : closest; face = h ? 4u : face; any |= h;
-    h = hit_rect<2>(py, py + sy, pz, pz + sz, px, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 5u : face; any |= h;
+    h = hit_rect<0, DEGENERATE>(px, px + sx, py, py + sy, pz + sz, r, tmin, closest, t); closest = h ? t : closest; face = h ? 0u : face; any |= h;
+    h = hit_rect<0, DEGENERATE>(px, px + sx, py, py + sy, pz, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 1u : face; any |= h;
+    h = hit_rect<1, DEGENERATE>(px, px + sx, pz, pz + sz, py + sy, r, tmin, closest, t); closest = h ? t : closest; face = h ? 2u : face; any |= h;
+    h = hit_rect<1, DEGENERATE>(px, px + sx, pz, pz + sz, py, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 3u : face; any |= h;
+    h = hit_rect<2, DEGENERATE>(py, py + sy, pz, pz + sz, px + sx, r, tmin, closest, t); closest = h ? t : closest; face = h ? 4u : face; any |= h;
+    h = hit_rect<2, DEGENERATE>(py, py + sy, pz, pz + sz, px, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 5u : face; any |= h;
     t_out = closest;
     return any;
+}
+// q4 = (size.y, size.z, degenerate flag: some size component is negative, -)
+__device__ __forceinline__ bool hit_rect3d(float4 q3, float4 q4, const Ray &r, float tmin, float tmax, float &t_out, uint32_t &face) {
+    if (q4.z != 0.f) return hit_rect3d_t<true>(q3, q4, r, tmin, tmax, t_out, face);
+    return hit_rect3d_t<false>(q3, q4, r, tmin, tmax, t_out, face);
 }
 
 constexpr float PI_F = 3.14159265358979323846f;
@@ -598,7 +616,7 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
     prim = 0;
     switch (kind) {
     case 0: return hit_sphere(q3.x, r, tmin, tmax, t);
-    case 1: case 2: case 3: return hit_rect_kind(kind, q3, q4.x, r, tmin, tmax, t);
+    case 1: case 2: case 3: return hit_rect_kind(kind, q3, q4, r, tmin, tmax, t);
     case 4: return hit_rect3d(q3, q4, r, tmin, tmax, t, prim);
     case 5: return hit_mesh(sc, aux0, aux1, r, tmin, tmax, tmax, stack_base, t, prim);
     case 7: return hit_cone(q3.x, q3.y, r, tmin, tmax, t);

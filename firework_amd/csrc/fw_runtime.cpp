@@ -348,16 +348,24 @@ struct Flattener {
             return FW_OK;
         case FW_SHAPE_XYRECT: case FW_SHAPE_XZRECT: case FW_SHAPE_YZRECT: {   // rect.rs:75-85
             sp.q3[0] = s.a_min; sp.q3[1] = s.a_max; sp.q3[2] = s.b_min; sp.q3[3] = s.b_max; sp.q4[0] = s.k;
+            sp.q4[1] = (s.a_min <= s.a_max && s.b_min <= s.b_max) ? 0.f : 1.f;      // an interval with lo > hi admits nothing (hit_rect)
             if (s.flip_normal) sp.flags |= fw::OF_RECT_FLIP;
             int a1 = s.kind == FW_SHAPE_YZRECT ? 1 : 0, a2 = s.kind == FW_SHAPE_XYRECT ? 1 : 2, ot = s.kind == FW_SHAPE_XYRECT ? 2 : (s.kind == FW_SHAPE_XZRECT ? 1 : 0);
             float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
             mn[a1] = s.a_min; mn[a2] = s.b_min; mn[ot] = s.k - 0.01f;
             mx[a1] = s.a_max; mx[a2] = s.b_max; mx[ot] = s.k + 0.01f;
             sp.box = {{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}};
+            if (sp.q4[1] != 0.f) {   // inverted box: like Disk, reachable under use_bvh only through the reference's leaf-node box
+                sp.flags |= fw::OF_GATE;
+                sp.true_box = {vmin(sp.box.mn, sp.box.mx), vmax(sp.box.mn, sp.box.mx)};
+            }
             return FW_OK; }
         case FW_SHAPE_RECT3D:                                        // rect3d.rs:102-104
             sp.q3[0] = s.pos.x; sp.q3[1] = s.pos.y; sp.q3[2] = s.pos.z; sp.q3[3] = s.size.x; sp.q4[0] = s.size.y; sp.q4[1] = s.size.z;
+            // a negative size turns some faces' bounds into lo > hi (hit_rect); pos + size is what the faces use (rect3d.rs:30-75)
+            sp.q4[2] = (s.pos.x <= s.pos.x + s.size.x && s.pos.y <= s.pos.y + s.size.y && s.pos.z <= s.pos.z + s.size.z) ? 0.f : 1.f;
             sp.box = {tov(s.pos), tov(s.pos) + tov(s.size)};
+            if (sp.q4[2] != 0.f) { sp.flags |= fw::OF_GATE; sp.true_box = {vmin(sp.box.mn, sp.box.mx), vmax(sp.box.mn, sp.box.mx)}; }   // as above
             return FW_OK;
         case FW_SHAPE_CONE: case FW_SHAPE_CYLINDER:                 // cone.rs:90-95, cylinder.rs:92-97
             sp.q3[0] = s.radius; sp.q3[1] = s.height; sp.q3[2] = s.phi_max;
@@ -489,7 +497,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         int32_t material = desc->shapes[o.shape].material;
         float *q = &objs[(size_t)i * fw::OBJ_Q * 4];
         const float pos[3] = {o.position.x, o.position.y, o.position.z};
-        if (kind == FW_SHAPE_RECT3D || kind == FW_SHAPE_TRIANGLE_MESH || kind == FW_SHAPE_CONE || kind == FW_SHAPE_CYLINDER) flags |= fw::OF_CULL0;
+        if ((kind == FW_SHAPE_RECT3D && sp.q4[2] == 0.f) || kind == FW_SHAPE_TRIANGLE_MESH || kind == FW_SHAPE_CONE || kind == FW_SHAPE_CYLINDER) flags |= fw::OF_CULL0;
         q[0] = pos[0]; q[1] = pos[1]; q[2] = pos[2]; q[3] = bits_f(kind | (flags << 8) | (inner << 24));
         std::memcpy(q + 4, sp.q3, 16);
         std::memcpy(q + 8, sp.q4, 16);

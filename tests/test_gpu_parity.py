@@ -202,6 +202,25 @@ def test_image_does_not_depend_on_the_walked_tree(monkeypatch):
         assert np.array_equal(sah.linear, med.linear), name
 
 
+def test_degenerate_rect_bounds_admit_nothing_as_in_the_reference(oracle):
+    """rect.rs:55-62 rejects on `x < min || x > max`, so an interval with min > max admits nothing: an XZRect given with
+    swapped bounds is invisible, and a Rect3d with a negative size keeps only the faces whose own bounds are in order.
+    (hit_rect's median form needs lo <= hi and hands these to the difference form.)"""
+    sc = Scene.new()
+    grey = sc.add_material(LambertianMat.with_color((0.6, 0.6, 0.6)))
+    red = sc.add_material(LambertianMat.with_color((0.8, 0.1, 0.1)))
+    green = sc.add_material(LambertianMat.with_color((0.1, 0.8, 0.1)))
+    sc.add_object(RenderObject.new(XZRect.new(-20.0, 20.0, -20.0, 20.0, 0.0, grey)))
+    sc.add_object(RenderObject.new(XYRect.new(2.0, -2.0, 0.0, 3.0, 1.0, red)))                      # a_min > a_max: never hit
+    sc.add_object(RenderObject.new(Rect3d.with_size((1.5, 1.5, -1.5), green)).position(-3.0, 0.0, 0.0))
+    sc.add_object(RenderObject.new(Rect3d.with_size((1.0, 2.0, 1.0), red)).rotate(Rotor3.from_rotation_xz(0.5)).position(1.5, 0.0, -1.0))
+    sc.set_environment(SkyEnv.default())
+    cam = CameraSettings.default().cam_pos((0.5, 3.0, -9.0)).look_at((0.0, 1.0, 0.0))
+    for bvh in (False, True):
+        r = Renderer.default().width(64).height(48).samples(16).use_bvh(bvh).camera(cam).seed(77)
+        check(oracle, sc, r)
+
+
 def test_fused_bounce_kernel_is_bit_identical_to_the_split_kernels(monkeypatch):
     """FIREWORK_FUSED=1 intersects and shades in one launch per segment (k_bounce) with the device functions of
     k_extend / k_shade: same bits, same ray counts, linear scan and TLAS."""
