@@ -3,12 +3,15 @@
 // Replaces the body of the reference's `Renderer::render()` pixel loop (src/render.rs:127-196):
 //
 //   k_raygen      render_pixel's loop head + Camera::ray          render.rs:172-180, camera.rs:109-116
-//   k_extend      root.hit(): linear scene / TLAS + per-object     scene.rs:137-149,235-266, bvh.rs:115-151,
+//   k_extend_linear / k_extend_bvh
+//                 root.hit(): linear scene / TLAS + per-object     scene.rs:137-149,235-266, bvh.rs:115-151,
 //                 transform + primitive intersectors + mesh BLAS   objects/*.rs
+//                 (one body, two entry points with their own register budgets)
 //   k_shade       Material::emit/scatter, Texture::sample,         render.rs:19-31, material.rs, texture.rs,
 //                 Environment::sample, + stream compaction         environment.rs
 //   k_accumulate  `total_color += color(..)` in sample order      render.rs:181
 //   k_resolve     /spp, powf(1/gamma), clamp, Color::from          render.rs:184-190, util.rs:14-23
+//   k_bounce      k_extend + k_shade of one segment in one launch (FIREWORK_FUSED=1; measured slower, kept for A/B)
 //
 // One lane = one path.  Path state lives in HBM as SoA arrays.  The path pool is split into WAVE-PRIVATE
 // queues: wavefront w owns slots [w*cap, (w+1)*cap) of every array and compacts its
