@@ -385,15 +385,17 @@ __device__ __forceinline__ bool hit_rect_kind(uint32_t kind, float4 q3, float4 q
 template <bool DEGENERATE>
 __device__ __forceinline__ bool hit_rect3d_t(float4 q3, float4 q4, const Ray &r, float tmin, float tmax, float &t_out, uint32_t &face) {
     float px = q3.x, py = q3.y, pz = q3.z, sx = q3.w, sy = q4.x, sz = q4.y;
-    bool any = false; float closest = tmax, t; face = 0;
+    float closest = tmax, t; face = 7u;          // 7 = no face yet: "any hit" is one vector compare at the end, not five scalar ORs
     bool h;   // predicated: no exec-mask bookkeeping between the six faces
-    h = hit_rect<0, DEGENERATE>(px, px + sx, py, py + sy, pz + sz, r, tmin, closest, t); closest = h ? t : closest; face = h ? 0u : face; any |= h;
-    h = hit_rect<0, DEGENERATE>(px, px + sx, py, py + sy, pz, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 1u : face; any |= h;
-    h = hit_rect<1, DEGENERATE>(px, px + sx, pz, pz + sz, py + sy, r, tmin, closest, t); closest = h ? t : closest; face = h ? 2u : face; any |= h;
-    h = hit_rect<1, DEGENERATE>(px, px + sx, pz, pz + sz, py, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 3u : face; any |= h;
-    h = hit_rect<2, DEGENERATE>(py, py + sy, pz, pz + sz, px + sx, r, tmin, closest, t); closest = h ? t : closest; face = h ? 4u : face; any |= h;
-    h = hit_rect<2, DEGENERATE>(py, py + sy, pz, pz + sz, px, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 5u : face; any |= h;
+    h = hit_rect<0, DEGENERATE>(px, px + sx, py, py + sy, pz + sz, r, tmin, closest, t); closest = h ? t : closest; face = h ? 0u : face;
+    h = hit_rect<0, DEGENERATE>(px, px + sx, py, py + sy, pz, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 1u : face;
+    h = hit_rect<1, DEGENERATE>(px, px + sx, pz, pz + sz, py + sy, r, tmin, closest, t); closest = h ? t : closest; face = h ? 2u : face;
+    h = hit_rect<1, DEGENERATE>(px, px + sx, pz, pz + sz, py, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 3u : face;
+    h = hit_rect<2, DEGENERATE>(py, py + sy, pz, pz + sz, px + sx, r, tmin, closest, t); closest = h ? t : closest; face = h ? 4u : face;
+    h = hit_rect<2, DEGENERATE>(py, py + sy, pz, pz + sz, px, r, tmin, closest, t);      closest = h ? t : closest; face = h ? 5u : face;
     t_out = closest;
+    const bool any = face != 7u;
+    face &= 7u * (uint32_t)any;                 // callers read `face` only after a hit, but keep it a valid face id
     return any;
 }
 // q4 = (size.y, size.z, degenerate flag: some size component is negative, -)
@@ -711,22 +713,32 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
             ainv = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
             eps = 1e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
         }
-        for (uint32_t k = 0; k < sc.n_objects; k++) {
-            Obj o = load_obj(sc.obj, k);     // wave-uniform index: scalar loads
-            if (cull0 && (obj_flags(o) & OF_CULL0)) {
-                const float4 lo = sc.obj_cull[2 * (size_t)k], hi = sc.obj_cull[2 * (size_t)k + 1];
-                const float m = eps + 1e-4f * (fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fabsf(lo.z)) + fmaxf(fmaxf(fabsf(hi.x), fabsf(hi.y)), fabsf(hi.z))) + 1e-6f;
-                float t0 = (lo.x - m - r.o.x) * ainv.x, t1 = (hi.x + m - r.o.x) * ainv.x;
-                float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-                t0 = (lo.y - m - r.o.y) * ainv.y; t1 = (hi.y + m - r.o.y) * ainv.y;
-                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-                t0 = (lo.z - m - r.o.z) * ainv.z; t1 = (hi.z + m - r.o.z) * ainv.z;
-                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
-                const bool maybe = !(tf < tn * (1.f - 1e-4f) - 1e-4f) && !(tf < 0.f);
-                if (__ballot(maybe) == 0ull) continue;
+        if (cull0) {
+            for (uint32_t k = 0; k < sc.n_objects; k++) {
+                Obj o = load_obj(sc.obj, k);     // wave-uniform index: scalar loads
+                if (obj_flags(o) & OF_CULL0) {
+                    const float4 lo = sc.obj_cull[2 * (size_t)k], hi = sc.obj_cull[2 * (size_t)k + 1];
+                    const float m = eps + 1e-4f * (fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fabsf(lo.z)) + fmaxf(fmaxf(fabsf(hi.x), fabsf(hi.y)), fabsf(hi.z))) + 1e-6f;
+                    float t0 = (lo.x - m - r.o.x) * ainv.x, t1 = (hi.x + m - r.o.x) * ainv.x;
+                    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+                    t0 = (lo.y - m - r.o.y) * ainv.y; t1 = (hi.y + m - r.o.y) * ainv.y;
+                    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                    t0 = (lo.z - m - r.o.z) * ainv.z; t1 = (hi.z + m - r.o.z) * ainv.z;
+                    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                    const bool maybe = !(tf < tn * (1.f - 1e-4f) - 1e-4f) && !(tf < 0.f);
+                    if (__ballot(maybe) == 0ull) continue;
+                }
+                float t; uint32_t prim;
+                if (hit_object(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
             }
-            float t; uint32_t prim;
-            if (hit_object(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+        } else {
+            // the loop of all later segments: no pre-test, nothing but the scan (the scalar unit is as busy as the VALUs here)
+            const float4 *op = sc.obj;
+            for (uint32_t k = 0; k < sc.n_objects; k++, op += OBJ_Q) {
+                Obj o = load_obj(op, 0);
+                float t; uint32_t prim;
+                if (hit_object(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+            }
         }
     } else {
         // bvh.rs:88-98,115-151 over RenderObjectInternal items; same scheme as hit_mesh
