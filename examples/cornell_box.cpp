@@ -1,5 +1,6 @@
 // examples/cornell_box.cpp — the reference's examples/cornell_box.rs, line for line, on include/firework.hpp.
-// usage: cornell_box [width height samples [out.ppm]]   (defaults 300 300 1000 as in the reference's main())
+// usage: cornell_box [width height samples [out.ppm [passes]]]   (defaults 300 300 1000 as in the reference's main();
+//        passes > 1: progressive render, the image is rewritten after every pass and ends up bit-identical)
 #include "firework.hpp"
 
 #include <chrono>
@@ -44,7 +45,15 @@ int main(int argc, char **argv) {
 
     fw_stats st{};
     std::vector<Color> render;
-    try { render = renderer.render(scene, &st); }
+    const size_t passes = argc > 5 ? strtoul(argv[5], nullptr, 10) : 1;
+    try {
+        if (passes > 1) {
+            render = renderer.render_progressive(scene, passes, [&](size_t k, const std::vector<Color> &img) {
+                std::printf("pass %zu of %zu\n", k + 1, passes);
+                if (argc > 4) save_image_ppm(img, argv[4], width, height);
+            });
+        } else render = renderer.render(scene, &st);
+    }
     catch (const std::exception &e) { std::fprintf(stderr, "render failed: %s\n", e.what()); return 1; }
 
     auto end = std::chrono::steady_clock::now();

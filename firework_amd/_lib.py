@@ -49,6 +49,9 @@ def load():
     lib.fw_render_scene.restype = C.c_int
     lib.fw_render_scene.argtypes = [C.POINTER(A.fw_scene_desc), C.POINTER(A.fw_render_params), C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.POINTER(A.fw_stats)]
+    lib.fw_render_progressive.restype = C.c_int
+    lib.fw_render_progressive.argtypes = [C.c_void_p, C.POINTER(A.fw_render_params), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.POINTER(A.fw_stats)]
     lib.fw_release_workspace.restype = None
     lib.fw_release_workspace.argtypes = [C.c_int]
     lib.fw_selftest_arith.restype = C.c_int
@@ -110,6 +113,22 @@ class DeviceScene:
         lin = np.empty((n, 3), np.float32)
         _check(lib, lib.fw_render(self.handle, C.byref(p), rgb8.ctypes.data, gam.ctypes.data, lin.ctypes.data,
                                   C.byref(st)))
+        return RenderResult(rgb8, gam, lin, st.as_dict(), p.width, p.height)
+
+    def render_progressive(self, renderer, first_sample, accum, pixel_ids=None):
+        """fw_render_progressive: adds samples [first_sample, first_sample + renderer's samples) to `accum`
+        ((n_pixels, 4) float32, zeros before the first call; updated in place) and returns the image resolved so far."""
+        from .api import RenderResult
+        lib = self._lib
+        p = renderer.to_params(pixel_ids)
+        n = int(pixel_ids.shape[0]) if pixel_ids is not None else p.width * p.height
+        assert accum.dtype == np.float32 and accum.shape == (n, 4) and accum.flags["C_CONTIGUOUS"]
+        st = A.fw_stats()
+        rgb8 = np.empty((n, 3), np.uint8)
+        gam = np.empty((n, 3), np.float32)
+        lin = np.empty((n, 3), np.float32)
+        _check(lib, lib.fw_render_progressive(self.handle, C.byref(p), int(first_sample), accum.ctypes.data, rgb8.ctypes.data,
+                                              gam.ctypes.data, lin.ctypes.data, C.byref(st)))
         return RenderResult(rgb8, gam, lin, st.as_dict(), p.width, p.height)
 
     def close(self):

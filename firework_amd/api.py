@@ -792,6 +792,40 @@ class Renderer:
         ids = None if pixel_ids is None else np.ascontiguousarray(np.asarray(pixel_ids, dtype=np.uint32))
         return _lib.render_scene(sd, self, ids, device)
 
+    def render_progressive(self, scene, passes: int, device: int = 0, checkpoint: Optional[str] = None):
+        """Progressive preview / resumable render (not in the reference): yields a RenderResult after each of
+        `passes` passes that split the samples evenly; the last one is bit-identical to `render_full`.  With `checkpoint`
+        (an .npz path) the accumulation buffer is saved after every pass and a matching file is resumed from."""
+        import copy
+        from . import _lib
+        sd = scene if isinstance(scene, SceneDesc) else scene.to_desc()
+        s = self.settings
+        total, n = int(s["samples"]), int(s["width"]) * int(s["height"])
+        passes = max(1, min(int(passes), total))
+        accum, done = np.zeros((n, 4), np.float32), 0
+        tag = np.array([s["width"], s["height"], s["seed"] & 0xffffffff, s["seed"] >> 32], dtype=np.int64)
+        if checkpoint:
+            import os
+            if os.path.exists(checkpoint):
+                ck = np.load(checkpoint)
+                if ck["accum"].shape == accum.shape and np.array_equal(ck["tag"], tag) and 0 < int(ck["done"]) <= total:
+                    accum, done = np.ascontiguousarray(ck["accum"], dtype=np.float32), int(ck["done"])
+        ds = _lib.DeviceScene(sd, device)
+        try:
+            bounds = [round(total * k / passes) for k in range(passes + 1)]
+            for k in range(passes):
+                lo, hi = max(bounds[k], done), bounds[k + 1]
+                if hi <= lo:
+                    continue
+                r = copy.copy(self); r.settings = dict(self.settings); r.settings["samples"] = hi - lo
+                res = ds.render_progressive(r, lo, accum)
+                done = hi
+                if checkpoint:
+                    np.savez(checkpoint, accum=accum, done=np.int64(done), tag=tag)
+                yield res
+        finally:
+            ds.close()
+
     def render(self, scene, device: int = 0) -> np.ndarray:
         """`pub fn render(&self, scene: Scene) -> Vec<Color>` (render.rs:109): (W*H, 3) uint8, row 0 = top."""
         return self.render_full(scene, None, device).rgb8

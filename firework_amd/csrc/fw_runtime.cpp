@@ -689,7 +689,9 @@ uint32_t default_paths_per_batch() {
     return (uint32_t)std::max<uint64_t>(budget, 1u << 16);
 }
 
-int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats) {
+// first_sample / user_accum: fw_render_progressive (0 / nullptr for a plain render)
+int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats,
+                uint32_t first_sample = 0, float *user_accum = nullptr) {
     if (!sc || !p) return fail(FW_ERR_BAD_ARG, "null argument");
     if (p->width == 0 || p->height == 0 || p->samples == 0) return fail(FW_ERR_BAD_ARG, "width, height and samples must be > 0");
     if (!(p->gamma > 0.f)) return fail(FW_ERR_BAD_ARG, "gamma must be > 0");
@@ -698,6 +700,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     if (full > 0xffffffffull) return fail(FW_ERR_UNSUPPORTED, "image too large");
     uint32_t n_pix = p->pixel_ids ? p->n_pixels : (uint32_t)full;
     if (n_pix == 0) return fail(FW_ERR_BAD_ARG, "no pixels to render");
+    if ((uint64_t)first_sample + p->samples > 0xffffffffull) return fail(FW_ERR_BAD_ARG, "first_sample + samples overflows");
     if (p->pixel_ids) for (uint32_t i = 0; i < n_pix; i++) if (p->pixel_ids[i] >= full) return fail(FW_ERR_BAD_ARG, "pixel id out of range");
     HIPCHK(hipSetDevice(sc->device));
     hipStream_t stream = (hipStream_t)p->stream;
@@ -761,7 +764,9 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     while (ws->events.size() < 3 + (size_t)n_batches) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, ws->events.size() < 2 ? hipEventDefault : hipEventDisableTiming)); ws->events.push_back(e); }
 
     if (p->pixel_ids) HIPCHK(hipMemcpyAsync(ws->pixel_ids.p, p->pixel_ids, (size_t)n_pix * 4, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetAsync(ws->accum.p, 0, (size_t)n_pix * 16, stream));
+    if (user_accum)     // resume: the sums of the samples rendered so far (host or device memory, like the outputs)
+        HIPCHK(hipMemcpyAsync(ws->accum.p, user_accum, (size_t)n_pix * 16, p->outputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+    else HIPCHK(hipMemsetAsync(ws->accum.p, 0, (size_t)n_pix * 16, stream));
     HIPCHK(hipMemsetAsync(ws->totals.p, 0, (size_t)n_batches * fw::COUNT_STRIDE * 4, stream));
 
     fw::LaunchCfg cfg;
@@ -819,8 +824,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             if (timing) { (void)hipEventRecord(L.events[1 + ev_next[l]], ls); ev_next[l]++; ev_class[l].push_back(cls); }
         };
         if (timing && ev_next[l] == 0) (void)hipEventRecord(L.events[0], ls);
-        fr.sample0 = b * spp_b;
-        fr.spp_batch = std::min(spp_b, p->samples - fr.sample0);
+        fr.sample0 = first_sample + b * spp_b;
+        fr.spp_batch = std::min(spp_b, p->samples - b * spp_b);
         uint32_t n_paths = n_pix * fr.spp_batch;
         uint32_t *totals = (uint32_t *)ws->totals.p + (size_t)b * fw::COUNT_STRIDE;
         fw::DPaths buf[2];
@@ -846,7 +851,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     }
     if (n_lanes > 1) HIPCHK(hipStreamWaitEvent(stream, ws->events[3 + n_batches - 1], 0));    // join
     cfg.stream = stream;
-    fw::launch_resolve(cfg, fr, (const float4 *)ws->accum.p, p->samples, p->gamma, d_rgb8, d_gamma, d_linear);
+    fw::launch_resolve(cfg, fr, (const float4 *)ws->accum.p, first_sample + p->samples, p->gamma, d_rgb8, d_gamma, d_linear);
+    if (user_accum) HIPCHK(hipMemcpyAsync(user_accum, ws->accum.p, (size_t)n_pix * 16, p->outputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
     HIPCHK(hipEventRecord(ws->events[1], stream));
     HIPCHK(hipGetLastError());
 
@@ -960,6 +966,14 @@ int fw_render(fw_scene *scene, const fw_render_params *params, uint8_t *rgb8, fl
     try { return render_impl(scene, params, rgb8, gamma_rgb, linear_rgb, stats); }
     catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
     catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_render"); }
+}
+
+int fw_render_progressive(fw_scene *scene, const fw_render_params *params, uint32_t first_sample, float *accum,
+                          uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats) {
+    if (!accum) return fail(FW_ERR_BAD_ARG, "fw_render_progressive needs an accumulation buffer");
+    try { return render_impl(scene, params, rgb8, gamma_rgb, linear_rgb, stats, first_sample, accum); }
+    catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
+    catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_render_progressive"); }
 }
 
 int fw_render_scene(const fw_scene_desc *desc, const fw_render_params *params, int device, uint8_t *rgb8, float *gamma_rgb,

@@ -17,6 +17,7 @@
 #pragma once
 #include "firework_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -230,6 +231,29 @@ struct Renderer {   // render.rs:59-218; Default: 1920x1080, 128 spp, multithrea
         std::vector<Color> buffer(width_ * height_, Color{0, 0, 0});
         int rc = fw_render_scene(&low.desc, &p, device_, reinterpret_cast<uint8_t *>(buffer.data()), nullptr, nullptr, stats);
         if (rc != FW_OK) throw std::runtime_error(std::string(fw_strerror(rc)) + " | " + fw_last_error());   // the reference panics here
+        return buffer; }
+
+    // Progressive preview (not in the reference): `passes` passes over the samples, `on_pass(k, image)` after each; `accum`
+    // (width*height*4 floats) may be kept by the caller as a checkpoint.  The last image equals render()'s bit for bit.
+    template <class F>
+    std::vector<Color> render_progressive(const Scene &scene, size_t passes, F on_pass, std::vector<float> *accum_io = nullptr) const {
+        Lowered low(scene);
+        fw_scene *sc = nullptr;
+        int rc = fw_scene_create(&low.desc, device_, &sc);
+        if (rc != FW_OK) throw std::runtime_error(std::string(fw_strerror(rc)) + " | " + fw_last_error());
+        std::vector<float> local; std::vector<float> &accum = accum_io ? *accum_io : local;
+        accum.assign(width_ * height_ * 4, 0.f);
+        std::vector<Color> buffer(width_ * height_, Color{0, 0, 0});
+        passes = std::max<size_t>(1, std::min(passes, samples_));
+        for (size_t k = 0; k < passes; k++) {
+            const size_t lo = samples_ * k / passes, hi = samples_ * (k + 1) / passes;
+            if (hi == lo) continue;
+            fw_render_params p = params(); p.samples = (uint32_t)(hi - lo);
+            rc = fw_render_progressive(sc, &p, (uint32_t)lo, accum.data(), reinterpret_cast<uint8_t *>(buffer.data()), nullptr, nullptr, nullptr);
+            if (rc != FW_OK) { fw_scene_destroy(sc); throw std::runtime_error(std::string(fw_strerror(rc)) + " | " + fw_last_error()); }
+            on_pass(k, buffer);
+        }
+        fw_scene_destroy(sc);
         return buffer; }
 };
 

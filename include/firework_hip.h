@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 2
+#define FW_ABI_VERSION 3   /* 3: + fw_render_progressive */
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum fw_status {
@@ -240,6 +240,17 @@ void fw_scene_destroy(fw_scene *scene);
      linear_rgb : pre-gamma per-pixel sample mean          (render.rs:184) */
 int fw_render(fw_scene *scene, const fw_render_params *params,
               uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats);
+
+/* Progressive / resumable rendering (progressive preview, checkpointable accumulation buffer).
+   Renders the samples [first_sample, first_sample + params->samples) of every pixel, adds them to `accum`
+   (n_pixels x 4 floats: r, g, b sums and one pad; all zeros before the first call; host memory, or device memory when
+   params->outputs_on_device) and resolves accum / (first_sample + samples) into the output buffers (any may be NULL).
+   Every random draw is keyed by (pixel, ABSOLUTE sample index) and a pixel's sums are taken in sample order, so k calls
+   of n samples leave bit for bit the accum and the image of one call of k*n samples — whatever is done with `accum`
+   between the calls: show a preview, write it to disk, resume in another process.
+   Reference: render.rs:172-190 sums `samples` colours per pixel and divides once; there is no progressive mode there. */
+int fw_render_progressive(fw_scene *scene, const fw_render_params *params, uint32_t first_sample, float *accum,
+                          uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats);
 
 /* One-shot form with the reference's exact shape: `Renderer::render(&self, scene: Scene)`
    (render.rs:109): scene conversion + BVH build + render inside one call. */

@@ -39,3 +39,15 @@ def test_cpp_host_renders_the_same_bytes_as_the_python_host():
         h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert int(m.group(1)) == res.stats["rays"] and int(m.group(2)) == res.stats["samples"]
     assert m.group(3) == f"{h:016x}"
+
+
+@pytest.mark.gpu
+def test_cpp_progressive_render_ends_bit_identical():
+    """include/firework.hpp's render_progressive (fw_render_progressive through the C ABI): 3 passes, same image hash."""
+    _build()
+    one = subprocess.run([EXE, "40", "32", "12"], capture_output=True, text=True, timeout=120)
+    three = subprocess.run([EXE, "40", "32", "12", "/dev/null", "3"], capture_output=True, text=True, timeout=120)
+    assert one.returncode == 0 and three.returncode == 0, one.stderr + three.stderr
+    h1 = re.search(r"fnv1a=([0-9a-f]{16})", one.stdout).group(1)
+    h3 = re.search(r"fnv1a=([0-9a-f]{16})", three.stdout).group(1)
+    assert h1 == h3 and three.stdout.count("pass ") == 3

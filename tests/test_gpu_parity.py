@@ -221,6 +221,24 @@ def test_degenerate_rect_bounds_admit_nothing_as_in_the_reference(oracle):
         check(oracle, sc, r)
 
 
+def test_progressive_passes_and_a_resumed_checkpoint_equal_one_render(tmp_path):
+    """fw_render_progressive: draws are keyed by the absolute sample index and a pixel's sums are taken in sample order, so
+    k passes — also interrupted and resumed from the saved accumulation buffer — give the bits of one render."""
+    for name, bvh in (("C2_cornell_box", False), ("C3_suzanne", True)):
+        s, r = scenes.config(name, 48, 36, 21)
+        r.use_bvh(bvh)
+        full = r.render_full(s)
+        passes = list(r.render_progressive(s, 4))
+        assert len(passes) == 4 and sum(p.stats["samples"] for p in passes) == full.stats["samples"]
+        assert np.array_equal(passes[-1].linear, full.linear) and np.array_equal(passes[-1].rgb8, full.rgb8)
+        assert not np.array_equal(passes[0].linear, full.linear)            # a preview, not the final image
+        ck = str(tmp_path / f"{name}.npz")
+        gen = r.render_progressive(s, 3, checkpoint=ck)
+        next(gen); gen.close()                                                 # "killed" after the first pass
+        resumed = list(r.render_progressive(s, 3, checkpoint=ck))
+        assert len(resumed) == 2 and np.array_equal(resumed[-1].linear, full.linear)
+
+
 def test_fused_bounce_kernel_is_bit_identical_to_the_split_kernels(monkeypatch):
     """FIREWORK_FUSED=1 intersects and shades in one launch per segment (k_bounce) with the device functions of
     k_extend / k_shade: same bits, same ray counts, linear scan and TLAS."""
