@@ -414,3 +414,21 @@ def test_random_scenes(oracle, seed):
     sc, cam = _random_scene(seed)
     r = Renderer.default().width(72).height(48).samples(8).use_bvh(bool(seed % 2)).camera(cam).seed(seed * 1000003)
     check(oracle, sc, r, max_bad_pixels=12)      # ocml vs glibc ulps in sin/atan2/acos/log10/pow flip a few texels / Fresnel draws
+
+
+def test_cli_progressive_and_checkpoint_write_the_same_png(tmp_path):
+    """`python -m firework_amd` (main.rs:6-62 flags) with --progressive / --checkpoint ends with the PNG of a plain run."""
+    import subprocess, sys, os
+    from PIL import Image
+    from firework_amd.yaml_io import save_scene
+    scene, _ = scenes.suzanne()
+    yml = tmp_path / "s.yml"
+    save_scene(scene, yml)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, "-m", "firework_amd", "--scene-file", str(yml), "-s", "12", "--width", "64", "--height", "36"]
+    a, b, ck = tmp_path / "a.png", tmp_path / "b.png", tmp_path / "ck.npz"
+    out = subprocess.run(base + ["-o", str(a)], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "Finished Rendering in" in out.stdout, out.stderr
+    out = subprocess.run(base + ["-o", str(b), "--progressive", "3", "--checkpoint", str(ck)], cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.count("pass ") == 3, out.stderr
+    assert np.array_equal(np.asarray(Image.open(a)), np.asarray(Image.open(b))) and ck.exists()
