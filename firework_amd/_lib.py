@@ -49,6 +49,9 @@ def load():
     lib.fw_render_scene.restype = C.c_int
     lib.fw_render_scene.argtypes = [C.POINTER(A.fw_scene_desc), C.POINTER(A.fw_render_params), C.c_int, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.POINTER(A.fw_stats)]
+    lib.fw_render_scene_tiled.restype = C.c_int
+    lib.fw_render_scene_tiled.argtypes = [C.POINTER(A.fw_scene_desc), C.POINTER(A.fw_render_params), C.POINTER(C.c_int), C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(A.fw_stats)]
     lib.fw_render_progressive.restype = C.c_int
     lib.fw_render_progressive.argtypes = [C.c_void_p, C.POINTER(A.fw_render_params), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.POINTER(A.fw_stats)]
@@ -155,4 +158,20 @@ def render_scene(scene_desc, renderer, pixel_ids=None, device=0):
     st = A.fw_stats()
     _check(lib, lib.fw_render_scene(scene_desc.ptr(), C.byref(p), device, rgb8.ctypes.data, gam.ctypes.data,
                                     lin.ctypes.data, C.byref(st)))
+    return RenderResult(rgb8, gam, lin, st.as_dict(), p.width, p.height)
+
+
+def render_scene_tiled(scene_desc, renderer, devices):
+    """fw_render_scene_tiled: one process, one host thread per listed device, tiles scattered into host buffers."""
+    from .api import RenderResult
+    lib = load()
+    p = renderer.to_params(None)
+    n = p.width * p.height
+    rgb8 = np.empty((n, 3), np.uint8)
+    gam = np.empty((n, 3), np.float32)
+    lin = np.empty((n, 3), np.float32)
+    st = A.fw_stats()
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    _check(lib, lib.fw_render_scene_tiled(scene_desc.ptr(), C.byref(p), devs, len(devices), rgb8.ctypes.data, gam.ctypes.data,
+                                          lin.ctypes.data, C.byref(st)))
     return RenderResult(rgb8, gam, lin, st.as_dict(), p.width, p.height)

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -966,6 +967,69 @@ int fw_render(fw_scene *scene, const fw_render_params *params, uint8_t *rgb8, fl
     try { return render_impl(scene, params, rgb8, gamma_rgb, linear_rgb, stats); }
     catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
     catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_render"); }
+}
+
+// ---- single-process multi-GPU: one host thread per device, 16x16 tiles dealt diagonally (the scheme of firework_amd/tiles.py),
+// each device renders its pixels with the keys one GPU would use, results are scattered into the caller's buffers.
+int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *params, const int *devices, int n_devices,
+                          uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats) {
+    if (!desc || !params || !devices || n_devices <= 0) return fail(FW_ERR_BAD_ARG, "null argument");
+    if (params->pixel_ids || params->outputs_on_device) return fail(FW_ERR_BAD_ARG, "fw_render_scene_tiled renders whole frames into host buffers");
+    if (params->width == 0 || params->height == 0) return fail(FW_ERR_BAD_ARG, "width, height and samples must be > 0");
+    try {
+        const uint32_t W = params->width, H = params->height, TILE = 16, tx = (W + TILE - 1) / TILE, ty = (H + TILE - 1) / TILE;
+        const int N = n_devices;
+        std::vector<std::vector<uint32_t>> ids(N);
+        for (uint32_t t = 0; t < tx * ty; t++) {
+            const uint32_t owner = (t % tx + t / tx) % (uint32_t)N, y0 = (t / tx) * TILE, x0 = (t % tx) * TILE;
+            for (uint32_t y = y0; y < std::min(y0 + TILE, H); y++) for (uint32_t x = x0; x < std::min(x0 + TILE, W); x++) ids[owner].push_back(y * W + x);
+        }
+        struct Part { int rc = FW_OK; std::string err; fw_stats st{}; std::vector<uint8_t> c8; std::vector<float> cg, cl; double ms_scene = 0; };
+        std::vector<Part> parts(N);
+        std::vector<std::thread> threads;
+        for (int r = 0; r < N; r++) threads.emplace_back([&, r] {
+            Part &pt = parts[r];
+            const size_t n = ids[r].size();
+            if (n == 0) return;
+            try {
+                auto t0 = std::chrono::steady_clock::now();
+                fw_scene *sc = nullptr;
+                pt.rc = fw_scene_create(desc, devices[r], &sc);
+                if (pt.rc) { pt.err = g_last_error; return; }
+                pt.ms_scene = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                fw_render_params p = *params;
+                p.pixel_ids = ids[r].data(); p.n_pixels = (uint32_t)n; p.stream = nullptr;
+                if (rgb8) pt.c8.resize(n * 3);
+                if (gamma_rgb) pt.cg.resize(n * 3);
+                if (linear_rgb) pt.cl.resize(n * 3);
+                pt.rc = fw_render(sc, &p, rgb8 ? pt.c8.data() : nullptr, gamma_rgb ? pt.cg.data() : nullptr, linear_rgb ? pt.cl.data() : nullptr, &pt.st);
+                if (pt.rc) pt.err = g_last_error;
+                fw_scene_destroy(sc);
+            } catch (...) { pt.rc = FW_ERR_OOM; pt.err = "host allocation failed in a tile worker"; }
+        });
+        for (auto &t : threads) t.join();
+        for (int r = 0; r < N; r++) if (parts[r].rc) return fail(parts[r].rc, parts[r].err);
+        if (stats) std::memset(stats, 0, sizeof *stats);
+        for (int r = 0; r < N; r++) {
+            const Part &pt = parts[r];
+            for (size_t i = 0; i < ids[r].size(); i++) {     // the one "gather": <= W*H*27 bytes over PCIe, already in host memory here
+                const size_t d = (size_t)ids[r][i] * 3;
+                if (rgb8) std::memcpy(rgb8 + d, &pt.c8[i * 3], 3);
+                if (gamma_rgb) std::memcpy(gamma_rgb + d, &pt.cg[i * 3], 12);
+                if (linear_rgb) std::memcpy(linear_rgb + d, &pt.cl[i * 3], 12);
+            }
+            if (stats && !ids[r].empty()) {
+                stats->samples += pt.st.samples; stats->rays += pt.st.rays; stats->algorithmic_bytes += pt.st.algorithmic_bytes;
+                for (int k = 0; k < FW_MAX_SEGMENTS; k++) stats->rays_per_depth[k] += pt.st.rays_per_depth[k];
+                stats->ms_render = std::max(stats->ms_render, pt.st.ms_render); stats->ms_scene = std::max(stats->ms_scene, pt.ms_scene);
+                stats->n_batches = std::max(stats->n_batches, pt.st.n_batches);
+                stats->tlas_nodes = pt.st.tlas_nodes; stats->blas_nodes = pt.st.blas_nodes; stats->reserved = pt.st.reserved;
+            }
+        }
+        return FW_OK;
+    }
+    catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
+    catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_render_scene_tiled"); }
 }
 
 int fw_render_progressive(fw_scene *scene, const fw_render_params *params, uint32_t first_sample, float *accum,

@@ -224,12 +224,18 @@ struct Renderer {   // render.rs:59-218; Default: 1920x1080, 128 spp, multithrea
         p.camera = fw_camera_settings{lower(camera_.cam_pos_), lower(camera_.look_at_), camera_.vfov, camera_.aperture_, camera_.focus_dist_};
         return p; }
 
+    // several GPUs from this one process (fw_render_scene_tiled): the image does not depend on the list
+    Renderer devices(std::vector<int> d) && { devices_ = std::move(d); return std::move(*this); }
+    std::vector<int> devices_;
+
     // `pub fn render(&self, scene: Scene) -> Vec<Color>` (render.rs:109): row 0 = image top
     std::vector<Color> render(const Scene &scene, fw_stats *stats = nullptr) const {
         Lowered low(scene);
         fw_render_params p = params();
         std::vector<Color> buffer(width_ * height_, Color{0, 0, 0});
-        int rc = fw_render_scene(&low.desc, &p, device_, reinterpret_cast<uint8_t *>(buffer.data()), nullptr, nullptr, stats);
+        int rc = devices_.empty()
+                     ? fw_render_scene(&low.desc, &p, device_, reinterpret_cast<uint8_t *>(buffer.data()), nullptr, nullptr, stats)
+                     : fw_render_scene_tiled(&low.desc, &p, devices_.data(), (int)devices_.size(), reinterpret_cast<uint8_t *>(buffer.data()), nullptr, nullptr, stats);
         if (rc != FW_OK) throw std::runtime_error(std::string(fw_strerror(rc)) + " | " + fw_last_error());   // the reference panics here
         return buffer; }
 

@@ -241,6 +241,15 @@ void fw_scene_destroy(fw_scene *scene);
 int fw_render(fw_scene *scene, const fw_render_params *params,
               uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats);
 
+/* One-shot render of a whole frame on SEVERAL GPUs from ONE process (what a single Rust binary calls; the Python hosts of
+   this repo use one process per GPU and an RCCL gather instead): the frame is cut into 16x16 tiles dealt diagonally over the
+   devices, one host thread per device creates the scene there and renders its pixels — with the keys a single GPU would
+   use, so the image is bit-identical for any device list — and the tiles are scattered into the caller's host buffers.
+   `devices` may name a device more than once (its calls are serialised).  render.rs:127-131 shards pixels over rayon workers
+   the same way.  stats: counters summed, times = the slowest device. */
+int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *params, const int *devices, int n_devices,
+                          uint8_t *rgb8, float *gamma_rgb, float *linear_rgb, fw_stats *stats);
+
 /* Progressive / resumable rendering (progressive preview, checkpointable accumulation buffer).
    Renders the samples [first_sample, first_sample + params->samples) of every pixel, adds them to `accum`
    (n_pixels x 4 floats: r, g, b sums and one pad; all zeros before the first call; host memory, or device memory when

@@ -239,6 +239,19 @@ def test_progressive_passes_and_a_resumed_checkpoint_equal_one_render(tmp_path):
         assert len(resumed) == 2 and np.array_equal(resumed[-1].linear, full.linear)
 
 
+def test_single_process_tiled_render_is_bit_identical():
+    """fw_render_scene_tiled (one host thread per device, 16x16 tiles dealt diagonally, host-side scatter): the same bits and
+    counters as one device, here with device 0 listed three times (its calls are serialised); ragged frame sizes too."""
+    for name, w, h, bvh in (("C2_cornell_box", 72, 50, False), ("C3_suzanne", 64, 36, True)):
+        s, r = scenes.config(name, w, h, 9)
+        r.use_bvh(bvh)
+        one = r.render_full(s)
+        tiled = _lib.render_scene_tiled(s.to_desc(), r, [0, 0, 0])
+        assert np.array_equal(one.linear, tiled.linear) and np.array_equal(one.rgb8, tiled.rgb8) and np.array_equal(one.gamma, tiled.gamma)
+        assert one.stats["rays"] == tiled.stats["rays"] and one.stats["samples"] == tiled.stats["samples"]
+        assert one.stats["rays_per_depth"] == tiled.stats["rays_per_depth"]
+
+
 def test_fused_bounce_kernel_is_bit_identical_to_the_split_kernels(monkeypatch):
     """FIREWORK_FUSED=1 intersects and shades in one launch per segment (k_bounce) with the device functions of
     k_extend / k_shade: same bits, same ray counts, linear scan and TLAS."""
