@@ -138,6 +138,7 @@ struct LaunchCfg {
     uint32_t n_mat, n_tex;        // table sizes (for the LDS-resident copy in k_shade)
     bool lds_tables;              // stage small scene tables in LDS (debug switch: FIREWORK_NO_LDS_TABLES)
     bool has_mesh;
+    bool tlas_refill;     // k_extend_tlas for use_bvh scenes without meshes (FIREWORK_TLAS_REFILL=0: the chunked k_extend_bvh)
 };
 constexpr size_t LDS_TABLE_LIMIT = 16 * 1024;   // object+material+texture tables up to this size are staged in LDS
 

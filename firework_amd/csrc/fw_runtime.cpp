@@ -778,6 +778,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.n_mat = sc->n_mat; cfg.n_tex = sc->n_tex;
     cfg.lds_tables = getenv("FIREWORK_NO_LDS_TABLES") == nullptr;
     cfg.has_mesh = sc->d.has_mesh != 0;
+    { const char *tr = getenv("FIREWORK_TLAS_REFILL"); cfg.tlas_refill = !(tr && atoi(tr) == 0); }
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;

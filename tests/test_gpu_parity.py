@@ -413,7 +413,9 @@ def _random_scene(seed):
     verts = np.array([[math.cos(2 * math.pi * k / n), math.sin(2 * math.pi * k / n), u(-0.2, 0.2)] for k in range(n)] + [[0, 0, 0.5]], np.float32)
     idx = [v for k in range(n) for v in (n, k, (k + 1) % n)]
     nrm = verts / np.maximum(np.linalg.norm(verts, axis=1, keepdims=True), 1e-3)
-    sc.add_object(RenderObject.new(TriangleMesh.new(verts, idx, nrm if seed % 2 else None, None, pick())).rotate(rot()).position(u(-2, 2), 1.5, u(-2, 2)))
+    mesh = RenderObject.new(TriangleMesh.new(verts, idx, nrm if seed % 2 else None, None, pick())).rotate(rot()).position(u(-2, 2), 1.5, u(-2, 2))
+    if seed % 4 != 3:      # every fourth scene has no mesh: under use_bvh those take k_extend_tlas, the others k_extend_bvh
+        sc.add_object(mesh)
     # checker floor NOT on the plane y = 0: there CheckerTexture's sign(sin(scale*y)) is the sign of a rounding
     # residue, i.e. noise in the reference itself, and any ulp upstream (log10f in a medium) flips the colour
     sc.add_object(RenderObject.new(XZRect.new(-30.0, 30.0, -30.0, 30.0, -0.37, mats[1])))
