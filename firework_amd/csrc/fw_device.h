@@ -125,6 +125,14 @@ struct DQueue {
     uint32_t *wcount;
 };
 
+// Rays that reached a mesh leaf of the TLAS, parked by k_extend_tlas_park for k_blas: wave w appends to its own
+// [w*cap, (w+1)*cap) like every queue; pcount[w] = how many.  40 B per parked ray: the world ray + (slot, mesh object,
+// best t so far, best hit code so far).
+struct DPark {
+    float4 *ray_a; float2 *ray_b; float4 *meta;
+    uint32_t *pcount;
+};
+
 constexpr uint32_t MISS = 0xffffffffu;
 constexpr int MAX_SEGMENTS = 11;
 constexpr int COUNT_STRIDE = 16;  // u32 counters per batch: [0..10] queue sizes, [11] spare
@@ -138,12 +146,12 @@ struct LaunchCfg {
     uint32_t n_mat, n_tex;        // table sizes (for the LDS-resident copy in k_shade)
     bool lds_tables;              // stage small scene tables in LDS (debug switch: FIREWORK_NO_LDS_TABLES)
     bool has_mesh;
-    bool tlas_refill;     // k_extend_tlas for use_bvh scenes without meshes (FIREWORK_TLAS_REFILL=0: the chunked k_extend_bvh)
+    bool tlas_refill;     // refilling walks: k_extend_tlas (no meshes) / k_extend_tlas_park + k_blas (meshes); FIREWORK_TLAS_REFILL=0: the chunked k_extend_bvh
 };
 constexpr size_t LDS_TABLE_LIMIT = 16 * 1024;   // object+material+texture tables up to this size are staged in LDS
 
 void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, float4 *sample_rad, uint32_t n_paths);
-void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float2 *hits, int segment, bool use_bvh);
+void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float2 *hits, int segment, bool use_bvh, DPark park);
 void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment);
 void launch_bounce(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, float4 *sample_rad, int segment,

@@ -3,7 +3,7 @@
 // Replaces the body of the reference's `Renderer::render()` pixel loop (src/render.rs:127-196):
 //
 //   k_raygen      render_pixel's loop head + Camera::ray          render.rs:172-180, camera.rs:109-116
-//   k_extend_linear / k_extend_bvh
+//   k_extend_linear / k_extend_tlas / k_extend_tlas_park + k_blas (/ k_extend_bvh)
 //                 root.hit(): linear scene / TLAS + per-object     scene.rs:137-149,235-266, bvh.rs:115-151,
 //                 transform + primitive intersectors + mesh BLAS   objects/*.rs
 //                 (one body, two entry points with their own register budgets)
@@ -677,15 +677,16 @@ extern __shared__ uint32_t lds_stack[];
 #endif
 constexpr uint32_t DEFER_CAP = FW_BLAS_RUN_MIN + 64;        // entries; a chunk adds at most 64 and the list is emptied when it reaches BLAS_RUN_MIN
 constexpr uint32_t BLAS_RUN_MIN = FW_BLAS_RUN_MIN;     // parked rays that start a BLAS run (the more, the smaller the share of its tail)
-// the refilling TLAS walk is used for scenes WITHOUT meshes (k_extend_tlas); with meshes it would have to drain its lanes
-// before every BLAS run and needs 128 registers (suzanne 12.6 vs 11.8 ms), so those keep the chunked walk
-constexpr bool WALK_MESHES = false;
 #ifndef FW_TLAS_REFILL_MIN
 #define FW_TLAS_REFILL_MIN 16
 #endif
 #ifndef FW_TLAS_WAVES
 #define FW_TLAS_WAVES 5
 #endif
+#ifndef FW_BLAS_WAVES
+#define FW_BLAS_WAVES 5
+#endif
+
 constexpr uint32_t TLAS_REFILL_MIN = FW_TLAS_REFILL_MIN;   // idle lanes that trigger a refill of the TLAS walk
 constexpr uint32_t BLAS_REFILL_MIN = FW_BLAS_REFILL_MIN;   // idle lanes that trigger a refill inside a run
 #ifndef FW_BLAS_WALK_NUM
@@ -789,9 +790,9 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
     }
 }
 
-template <bool USE_BVH, bool REFILL>
+template <bool USE_BVH, bool REFILL, bool PARK>
 __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, const DPaths &in, float2 *__restrict__ hits,
-                                            const DQueue &q, int segment, int tlas_levels, int stack_levels) {
+                                            const DQueue &q, int segment, int tlas_levels, int stack_levels, const DPark &park) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     if (w >= q.n_waves) return;
     TS_BEGIN();
@@ -891,11 +892,11 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
         float best_t = TMAX; bool have = false, deferred = false;
         V3 wo = mk(0, 0, 0), wd = wo, inv = wo;
         LdsStack st{my_stack, 0};
-        bool draining = false;                                          // the parked list is full enough: no refills until the lanes are empty
+        uint32_t park_n = 0;                                            // rays handed over to k_blas so far (wave-uniform)
         for (;;) {
             const unsigned long long idle_mask = __ballot(slot == IDLE);
             const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-            if (q_next < n && !draining) {
+            if (q_next < n) {
                 if (n_idle >= TLAS_REFILL_MIN) {
                     const uint32_t take = min(n_idle, min(n, cur_base + 64u) - q_next);
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
@@ -925,11 +926,6 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                     }
                 }
             } else if (n_idle == 64u) {
-                if (WALK_MESHES && draining) {                          // every lane is empty: walk the parked rays, then go on
-                    blas_run();
-                    draining = false;
-                    continue;
-                }
                 break;                                                  // queue empty and every lane has retired its ray
             }
 
@@ -951,7 +947,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                 Obj o = load_obj_for_hit(sc.obj, item);
                 const bool gated_out = (obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)item], sc.obj_gate[2 * (size_t)item + 1], wo, inv, TMIN, TMAX);
                 if (!gated_out) {
-                    if (WALK_MESHES && sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = item; }   // park the first mesh
+                    if (PARK && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = item; }   // the first mesh: this ray goes to k_blas
                     else {
                         TS_TICK(2);
                         RngKey key{0, 0, 0};
@@ -967,21 +963,22 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
             // ---- retire the rays that are out of tree
             const bool done = slot != IDLE && cur == REF_DONE;
             if (done && !deferred) qst(&hits[base + slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
-            if (WALK_MESHES && sc.has_mesh) {
+            if (PARK) {          // dense append to the wave's parked queue: the world ray and what the TLAS walk found so far
                 const unsigned long long pmask = __ballot(done && deferred);
                 if (pmask) {
                     const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
                     if (done && deferred) {
-                        const uint32_t e = list_n + prank;
-                        e_slot[e] = base + slot; e_obj[e] = deferred_obj; e_t[e] = best_t; e_bobj[e] = best_obj; e_bprim[e] = best_prim;
+                        const uint32_t e = base + park_n + prank;
+                        qst(&park.ray_a[e], make_float4(wo.x, wo.y, wo.z, wd.x));
+                        qst(&park.ray_b[e], make_float2(wd.y, wd.z));
+                        qst(&park.meta[e], make_float4(__uint_as_float(base + slot), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
                     }
-                    list_n += (uint32_t)__popcll(pmask);
-                    if (list_n >= BLAS_RUN_MIN) draining = true;
+                    park_n += (uint32_t)__popcll(pmask);
                 }
             }
             if (done) slot = IDLE;
         }
-        if (WALK_MESHES && list_n) blas_run();
+        if (PARK && lane == 0) park.pcount[w] = park_n;
         TS_END();
         return;
     }
@@ -1026,16 +1023,110 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
 // 16.2 ms at equal settings; 6 waves spill and lose again.
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(7, 8)))
 void k_extend_linear(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
-    extend_body<false, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels);
+    extend_body<false, false, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
 }
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void k_extend_bvh(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
-    extend_body<true, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels);
+    extend_body<true, false, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
 }
 // scenes without meshes: the TLAS walk with in-wave refill (part2 @16 spp: 9.6 vs 10.5 ms)
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_TLAS_WAVES, 8)))
 void k_extend_tlas(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
-    extend_body<true, true>(sc, f, in, hits, q, segment, tlas_levels, stack_levels);
+    extend_body<true, true, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
+}
+// scenes with meshes: the same walk, but a ray that reaches a mesh is handed to k_blas through the wave's parked queue in HBM
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_TLAS_WAVES, 8)))
+void k_extend_tlas_park(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels, DPark park) {
+    extend_body<true, true, true>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, park);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4  k_blas: the mesh BLAS walks of the rays k_extend_tlas_park handed over, with in-wave refill.
+//
+// Wave w walks the rays of its parked queue: 64 start, and whenever BLAS_REFILL_MIN lanes have finished theirs the idle
+// lanes take the next ones — from a 64-entry register read-ahead of the queue (the parked entry carries the world ray, so
+// a refill costs one object-record fetch and the transform, not a chain of HBM round trips).  Same rounds, same
+// arithmetic and tie rules as hit_mesh; the finished ray is merged with what the TLAS walk held and its hit record written.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_BLAS_WAVES, 8)))
+void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
+    const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
+    if (w >= q.n_waves) return;
+    TS_BEGIN();
+    const uint32_t n = park.pcount[w];
+    const uint32_t base = w * q.cap;
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    float4 ca = make_float4(0, 0, 0, 0), na = ca, cm = ca, nm = ca; float2 cb = make_float2(0, 0), nb = cb;
+    auto fetch = [&](uint32_t j, float4 &a, float2 &b, float4 &m) {
+        if (j < n) { a = qld(&park.ray_a[base + j]); b = qld(&park.ray_b[base + j]); m = qld(&park.meta[base + j]); }
+    };
+    fetch(lane, ca, cb, cm); fetch(64u + lane, na, nb, nm);
+    uint32_t cur_base = 0, q_next = 0;
+    bool act = false, have = false;
+    uint32_t slot = 0, obj = 0, tri_base = 0, bcode = MISS, mtri = 0, cur = REF_DONE;
+    float bt = TMAX, mbest = TMAX;
+    V3 ro = mk(0, 0, 0), inv = ro;
+    TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
+    LdsStack st{lds_stack + threadIdx.x, 0};
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(!act);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (q_next < n) {
+            if (n_idle >= BLAS_REFILL_MIN) {
+                const uint32_t take = min(n_idle, min(n, cur_base + 64u) - q_next);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                const int sel = (int)((((q_next - cur_base) + rank) & 63u) << 2);
+                auto bp = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(v))); };
+                const float4 ra = make_float4(bp(ca.x), bp(ca.y), bp(ca.z), bp(ca.w));
+                const float2 rb = make_float2(bp(cb.x), bp(cb.y));
+                const float4 me = make_float4(bp(cm.x), bp(cm.y), bp(cm.z), bp(cm.w));
+                if (!act && rank < take) {
+                    slot = __float_as_uint(me.x); obj = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
+                    Obj o = load_obj(sc.obj, obj);
+                    Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
+                    ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                    tr = make_triray(r);
+                    tri_base = o.aux1; cur = o.aux0; st.sp = 0;
+                    have = false; mbest = TMAX; mtri = 0; act = true;
+                }
+                q_next += take;
+                if (q_next == cur_base + 64u && q_next < n) { ca = na; cb = nb; cm = nm; cur_base += 64u; fetch(cur_base + 64u + lane, na, nb, nm); }
+            }
+        } else if (n_idle == 64u) break;
+
+        const uint32_t n_act = (uint32_t)__popcll(__ballot(act));
+        for (;;) {   // node steps; the wave stops once no more than half of its busy lanes still walk (the others test their
+                     // triangle now, the walkers go on next round).  Counting only true leaf holders, or leaving early for a
+                     // refill, measured no better (11.1 vs 11.0 ms).
+            const bool walking = act && !(cur & REF_LEAF);
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+            if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
+            if (walking) {
+                TS_TICK(4);
+                cur = pair_step(sc.blas, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
+            }
+        }
+        if (act && (cur & REF_LEAF)) {
+            if (cur != REF_DONE) {
+                const uint32_t item = cur & NODE_MASK;
+                cur = st.sp ? st.pop() : REF_DONE;
+                TS_TICK(6);
+                const float4 *tp = sc.tri + 3 * (size_t)(tri_base + item);
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, b0, b1, b2;
+                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, TMIN, TMAX, t, b0, b1, b2)) {
+                    if (!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) { have = true; mbest = t; mtri = item; }
+                }
+            }
+            if (cur == REF_DONE) {                                      // finished: merge with what the TLAS walk held
+                const uint32_t bobj = bcode == MISS ? MISS : (bcode >> sc.prim_bits);
+                if (have && (bobj == MISS || mbest < bt || (mbest == bt && sc.obj_rank[obj] > sc.obj_rank[bobj]))) { bt = mbest; bcode = (obj << sc.prim_bits) | mtri; }
+                qst(&hits[slot], make_float2(bt, __uint_as_float(bcode)));
+                act = false;
+            }
+        }
+    }
+    TS_END();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1539,12 +1630,17 @@ static dim3 wave_grid(const LaunchCfg &c) { return dim3((c.q.n_waves + WB / 64 -
 void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPaths out, float4 *sample_rad, uint32_t n_paths) {
     hipLaunchKernelGGL(k_raygen, wave_grid(c), dim3(WB), 0, c.stream, cam, f, out, sample_rad, c.q, n_paths);
 }
-void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float2 *hits, int segment, bool use_bvh) {
+void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float2 *hits, int segment, bool use_bvh, DPark park) {
     int tl = use_bvh ? c.tlas_depth + 1 : 0;
     int levels = tl + c.blas_depth + 1;
     size_t lds = (size_t)levels * WB * sizeof(uint32_t) + (use_bvh && c.has_mesh ? 5 * DEFER_CAP * sizeof(uint32_t) : 0);
     dim3 eg = wave_grid(c);
-    if (use_bvh && !c.has_mesh && c.tlas_refill) hipLaunchKernelGGL(k_extend_tlas, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+    if (use_bvh && c.tlas_refill && c.has_mesh) {
+        // TLAS walk that parks mesh rays in HBM, then their BLAS walks; a medium around a mesh still walks it in place (blas levels)
+        hipLaunchKernelGGL(k_extend_tlas_park, eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
+        hipLaunchKernelGGL(k_blas, eg, dim3(WB), (size_t)(c.blas_depth + 1) * WB * sizeof(uint32_t), c.stream, sc, park, hits, c.q);
+    }
+    else if (use_bvh && c.tlas_refill) hipLaunchKernelGGL(k_extend_tlas, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }

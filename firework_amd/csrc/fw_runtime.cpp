@@ -277,7 +277,8 @@ struct DevBuf {
 // depend on n (batches are accumulated in order).  Default 1: the measured gain is ~3 %.
 struct Workspace {
     static constexpr int MAX_LANES = 4;
-    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, wcount; hipStream_t stream = nullptr; std::vector<hipEvent_t> events; };
+    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, wcount, park_a, park_b, park_m, pcount;
+                  hipStream_t stream = nullptr; std::vector<hipEvent_t> events; };
     std::mutex mu;                        // one fw_render at a time per device
     Lane lanes[MAX_LANES];
     DevBuf accum, totals, pixel_ids, out_rgb8, out_gamma, out_linear;
@@ -286,7 +287,7 @@ struct Workspace {
     void release() {
         for (DevBuf *b : {&accum, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear, &scene_cache}) b->release();
         for (Lane &l : lanes) {
-            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount}) b->release();
+            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount, &l.park_a, &l.park_b, &l.park_m, &l.pcount}) b->release();
             for (hipEvent_t e : l.events) (void)hipEventDestroy(e);
             l.events.clear();
             if (l.stream) (void)hipStreamDestroy(l.stream);
@@ -742,6 +743,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     if (cap64 > 0x7fffffffull) return fail(FW_ERR_UNSUPPORTED, "too many path slots");
     uint32_t cap = (uint32_t)cap64;
 
+    const bool tlas_refill = [] { const char *tr = getenv("FIREWORK_TLAS_REFILL"); return !(tr && atoi(tr) == 0); }();
+    const bool park_meshes = p->use_bvh && sc->d.has_mesh != 0 && tlas_refill;
     int rc = FW_OK;
     auto need = [&](DevBuf &b, size_t n) { if (!rc) rc = b.alloc(n); };
     for (int l = 0; l < n_lanes; l++) {
@@ -750,6 +753,9 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         need(L.hits, (size_t)cap * 8);
         need(L.sample_rad, (size_t)cap * 16);                 // indexed by home slot
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
+        if (park_meshes) {     // rays handed from k_extend_tlas_park to k_blas: 40 B per slot
+            need(L.park_a, (size_t)cap * 16); need(L.park_b, (size_t)cap * 8); need(L.park_m, (size_t)cap * 16); need(L.pcount, (size_t)q.n_waves * 4);
+        }
         if (!rc && !L.stream && n_lanes > 1) HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     }
     need(ws->accum, (size_t)n_pix * 16);
@@ -778,7 +784,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.n_mat = sc->n_mat; cfg.n_tex = sc->n_tex;
     cfg.lds_tables = getenv("FIREWORK_NO_LDS_TABLES") == nullptr;
     cfg.has_mesh = sc->d.has_mesh != 0;
-    { const char *tr = getenv("FIREWORK_TLAS_REFILL"); cfg.tlas_refill = !(tr && atoi(tr) == 0); }
+    cfg.tlas_refill = tlas_refill;
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
@@ -834,12 +840,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         for (int k = 0; k < 2; k++) buf[k] = {(float4 *)L.ray_a[k].p, (float2 *)L.ray_b[k].p, (float4 *)L.state[k].p};
         float2 *hits = (float2 *)L.hits.p;
         float4 *srad = (float4 *)L.sample_rad.p, *accum = (float4 *)ws->accum.p;
+        const fw::DPark park{(float4 *)L.park_a.p, (float2 *)L.park_b.p, (float4 *)L.park_m.p, (uint32_t *)L.pcount.p};
         int cur = 0;
         timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], srad, n_paths); });
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
             if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
             else {
-                timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh); });
+                timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park); });
                 timed(2, [&] { fw::launch_shade(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], hits, srad, seg); });
             }
             cur ^= 1;
