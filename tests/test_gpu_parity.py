@@ -252,6 +252,20 @@ def test_single_process_tiled_render_is_bit_identical():
         assert one.stats["rays_per_depth"] == tiled.stats["rays_per_depth"]
 
 
+def test_refilling_and_chunked_bvh_walks_are_bit_identical(monkeypatch):
+    """use_bvh scenes walk with in-wave ray refill (k_extend_tlas; with meshes k_extend_tlas_park + k_blas); the chunked
+    k_extend_bvh with its in-kernel BLAS runs stays selectable (FIREWORK_TLAS_REFILL=0): same bits, same ray counts."""
+    for name, w, h, spp in (("C3_suzanne", 96, 54, 12), ("C5_part2_all", 96, 54, 6), ("C1_random_spheres", 100, 56, 12)):
+        s, r = scenes.config(name, w, h, spp)
+        monkeypatch.delenv("FIREWORK_TLAS_REFILL", raising=False)
+        refill = r.render_full(s)
+        monkeypatch.setenv("FIREWORK_TLAS_REFILL", "0")
+        chunk = r.render_full(s)
+        monkeypatch.delenv("FIREWORK_TLAS_REFILL", raising=False)
+        assert refill.stats["rays_per_depth"] == chunk.stats["rays_per_depth"], name
+        assert np.array_equal(refill.linear, chunk.linear), name
+
+
 def test_fused_bounce_kernel_is_bit_identical_to_the_split_kernels(monkeypatch):
     """FIREWORK_FUSED=1 intersects and shades in one launch per segment (k_bounce) with the device functions of
     k_extend / k_shade: same bits, same ray counts, linear scan and TLAS."""
