@@ -681,13 +681,13 @@ fw::DCamera make_camera(const fw_camera_settings &s, uint32_t width, uint32_t he
 
 // Wavefront pool size.  Bigger is better on this part: fewer, fuller launches and longer wave-private queues
 // (measured on cornell 512x512@1024: 4 Mi paths 85 ms/frame, 16 Mi 64 ms, 256 Mi = the whole frame 55 ms).
-// Default: up to 2^28 paths (104 B per slot, and up to twice as many slots as paths because a wave's queue capacity is a
-// power of two: 28-56 GB), never more than half of the free HBM.
+// Default: up to 2^28 paths (104 B per slot + 40 B for parked mesh rays, and up to twice as many slots as paths because a
+// wave's queue capacity is a power of two: 28-77 GB), never more than half of the free HBM.
 uint32_t default_paths_per_batch() {
     if (const char *e = getenv("FIREWORK_PATHS_PER_BATCH")) { long long v = atoll(e); if (v > 0) return (uint32_t)std::min<long long>(v, 0x7fffffffll); }
     size_t free_b = 0, total_b = 0;
     uint64_t budget = 1ull << 28;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, (uint64_t)(free_b / 2) / 208u);
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, (uint64_t)(free_b / 2) / 288u);
     return (uint32_t)std::max<uint64_t>(budget, 1u << 16);
 }
 
