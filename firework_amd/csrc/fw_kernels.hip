@@ -687,6 +687,10 @@ constexpr uint32_t BLAS_RUN_MIN = FW_BLAS_RUN_MIN;     // parked rays that start
 #define FW_BLAS_WAVES 5
 #endif
 
+#ifndef FW_TLAS_SCAN_MAX
+#define FW_TLAS_SCAN_MAX 8
+#endif
+constexpr uint32_t TLAS_SCAN_MAX = FW_TLAS_SCAN_MAX;       // up to this many objects the TLAS is scanned, not walked
 constexpr uint32_t TLAS_REFILL_MIN = FW_TLAS_REFILL_MIN;   // idle lanes that trigger a refill of the TLAS walk
 constexpr uint32_t BLAS_REFILL_MIN = FW_BLAS_REFILL_MIN;   // idle lanes that trigger a refill inside a run
 #ifndef FW_BLAS_WALK_NUM
@@ -874,6 +878,60 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
         }
     };
 
+    if (USE_BVH && REFILL && sc.n_objects <= TLAS_SCAN_MAX) {
+        // ---- a TLAS of a handful of objects (suzanne: floor, light, mesh) is not walked but scanned: every lane tests every
+        // object's box (the very box and slab test its leaf has in the tree, culled against the best t like pair_step) and, where
+        // that passes, the object — with wave-uniform object indices, i.e. scalar loads and no divergence between lanes.  The
+        // tree walk reaches an object iff its own box passes (its ancestors' boxes are supersets, and the slab arithmetic is
+        // monotone), and ties are decided by rank, not by order, so the result is the tree walk's bit for bit
+        // (suzanne's k_extend_tlas_park: 3.5 of the 11 ms went into walking three objects).
+        uint32_t park_n = 0;
+        float4 ra_n = make_float4(0, 0, 0, 0); float2 rb_n = make_float2(0, 0);
+        if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); }
+        for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+            const uint32_t j = c0 + lane, i = base + j;
+            const float4 ra = ra_n; const float2 rb = rb_n;
+            if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); }
+            const bool active = j < n;
+            bool deferred = false, have = false; uint32_t deferred_obj = 0, best_obj = MISS, best_prim = 0; float best_t = TMAX;
+            Ray r{mk(0, 0, 0), mk(0, 0, 1)};
+            if (active) {
+                r = make_ray(ra, rb, f, segment);
+                RngKey key{0, 0, 0};
+                if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
+                const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                for (uint32_t k = 0; k < sc.n_objects; k++) {
+                    const float4 lo = sc.obj_cull[2 * (size_t)k], hi = sc.obj_cull[2 * (size_t)k + 1];   // the leaf's box in the walked tree
+                    float entry;
+                    if (!hit_aabb_entry(lo, hi, r.o, inv, TMIN, TMAX, entry) || entry > cull_bound(have ? best_t : TMAX)) continue;
+                    Obj o = load_obj(sc.obj, k);
+                    if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)k], sc.obj_gate[2 * (size_t)k + 1], r.o, inv, TMIN, TMAX)) continue;
+                    if (PARK && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = k; continue; }
+                    float t; uint32_t prim;
+                    if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+                        if (!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = k; best_prim = prim; }
+                    }
+                }
+                if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
+            }
+            if (PARK) {
+                const unsigned long long pmask = __ballot(deferred);
+                if (pmask) {
+                    const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
+                    if (deferred) {
+                        const uint32_t e = base + park_n + prank;
+                        qst(&park.ray_a[e], make_float4(r.o.x, r.o.y, r.o.z, r.d.x));
+                        qst(&park.ray_b[e], make_float2(r.d.y, r.d.z));
+                        qst(&park.meta[e], make_float4(__uint_as_float(i), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
+                    }
+                    park_n += (uint32_t)__popcll(pmask);
+                }
+            }
+        }
+        if (PARK && lane == 0) park.pcount[w] = park_n;
+        TS_END();
+        return;
+    }
     if (USE_BVH && REFILL) {
         // ---- TLAS walk with in-wave refill.  The chunked loop below gives every lane one ray of a 64-ray chunk and waits
         // for the slowest: on part2 only 40 % of the lanes are still busy in an average round (tools/trav_stats.py).  Here a
