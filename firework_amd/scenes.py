@@ -9,9 +9,9 @@ import os
 
 import numpy as np
 
-from .api import (CameraSettings, CheckerTexture, ConstantTexture, DielectricMat, EmissiveMat, HdrEnvironment,
-                  ImageTexture, LambertianMat, MetalMat, Rect3d, RenderObject, Renderer, Rotor3, Scene, SkyEnv,
-                  Sphere, TriangleMesh, TurbulenceTexture, XYRect, XZRect, YZRect, to_radians)
+from .api import (CameraSettings, CheckerTexture, Cone, ConstantTexture, Cylinder, DielectricMat, Disk, EmissiveMat,
+                  HdrEnvironment, ImageTexture, LambertianMat, MetalMat, Rect3d, RenderObject, Renderer, Rotor3, Scene,
+                  SkyEnv, Sphere, TriangleMesh, TurbulenceTexture, XYRect, XZRect, YZRect, to_radians)
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCENES_DIR = os.path.join(_ROOT, "scenes")
@@ -199,6 +199,77 @@ def part2_all(seed=12345):
     scene.add_volume(RenderObject.new(Sphere.new(5000.0, 0)), 0.0001, ConstantTexture.new((1.0, 1.0, 1.0)))
     camera = CameraSettings.default().cam_pos((-9.0, 3.0, -9.0)).look_at((1.0, 3.0, 2.0)).field_of_view(25.0)
     renderer = Renderer.default().width(600).height(800).samples(10000).use_bvh(True).camera(camera)
+    return scene, renderer
+
+
+def conics():
+    """examples/conics.rs:11-93 (= scenes/conics.yml): Cylinder / Disk / Cone, the partial cylinder twice (the inner
+    copy with flipped normals), an ImageTexture (uvmap.png), `from_euler_angles`.  960x540 @128, no BVH."""
+    scene = Scene.new()
+    uv_image_mat = scene.add_material(LambertianMat.new(ImageTexture.from_path(os.path.join(SCENES_DIR, "uvmap.png"))))
+    scene.add_object(RenderObject.new(Cylinder.new(2.0, 3.0, uv_image_mat)).position(-4.2, 0.0, 0.0))
+    blue = scene.add_material(LambertianMat.with_color((0.0, 0.2, 0.4)))
+    scene.add_object(RenderObject.new(Disk.new(2.0, blue)).position(-4.2, 3.0, 0.0))
+    scene.add_object(RenderObject.new(Cone.new(2.0, 3.0, uv_image_mat)).position(-1.0, 0.0, -4.0))
+    euler = lambda: Rotor3.from_euler_angles(to_radians(90.0), to_radians(30.0), to_radians(-35.0))
+    scene.add_object(RenderObject.new(Cylinder.partial(1.5, 3.0, 300.0, uv_image_mat)).position(3.0, 1.5, 1.0).rotate(euler()))
+    scene.add_object(RenderObject.new(Cylinder.partial(1.49, 3.0, 300.0, uv_image_mat)).position(3.0, 1.5, 1.0).rotate(euler())
+                     .flip_normals())
+    scene.add_object(RenderObject.new(Disk.partial(1.5, 300.0, 0.8, uv_image_mat)).position(3.0, 1.5, 1.0).rotate(euler()))
+    grey = scene.add_material(LambertianMat.with_color((0.5, 0.5, 0.5)))
+    scene.add_object(RenderObject.new(XZRect.new(-100.0, 100.0, -100.0, 100.0, 0.0, grey)))
+    light = scene.add_material(EmissiveMat.with_color((8.0, 8.0, 8.0)))
+    scene.add_object(RenderObject.new(YZRect.new(0.0, 20.0, 0.0, 10.0, -3.0, light))
+                     .rotate(Rotor3.from_rotation_xz(-30.0)).position(0.0, 0.0, -10.0))
+    scene.set_environment(SkyEnv.default())
+    camera = CameraSettings.default().cam_pos((6.0, 4.0, -7.0)).look_at((0.0, 1.5, 0.0)).field_of_view(60.0)
+    renderer = Renderer.default().width(960).height(540).samples(128).camera(camera)
+    return scene, renderer
+
+
+def earth():
+    """examples/earth.rs:12-53: four image-textured spheres (earthmap.jpg, uvmap.png).  800x800 @128, no BVH."""
+    scene = Scene.new()
+    earth_mat = scene.add_material(LambertianMat.new(ImageTexture.from_path(os.path.join(SCENES_DIR, "earthmap.jpg"))))
+    uv_image_mat = scene.add_material(LambertianMat.new(ImageTexture.from_path(os.path.join(SCENES_DIR, "uvmap.png"))))
+    scene.add_object(RenderObject.new(Sphere.new(0.25, earth_mat)))
+    scene.add_object(RenderObject.new(Sphere.new(0.25, uv_image_mat)).position(1.0, 0.0, 0.0))
+    scene.add_object(RenderObject.new(Sphere.new(0.25, earth_mat)).position(0.0, 1.0, 0.0))
+    scene.add_object(RenderObject.new(Sphere.new(0.25, earth_mat)).position(0.0, 0.0, 1.0))
+    grey = scene.add_material(LambertianMat.with_color((0.5, 0.5, 0.5)))
+    scene.add_object(RenderObject.new(XZRect.new(-100.0, 100.0, -100.0, 100.0, 0.0, grey)))
+    light = scene.add_material(EmissiveMat.with_color((8.0, 8.0, 8.0)))
+    scene.add_object(RenderObject.new(YZRect.new(0.0, 20.0, 0.0, 10.0, -3.0, light))
+                     .rotate(Rotor3.from_rotation_xz(-30.0)).position(0.0, 0.0, -10.0))
+    scene.set_environment(SkyEnv.default())
+    camera = CameraSettings.default().cam_pos((5.0, 5.0, 5.0)).look_at((0.0, 0.0, 0.0)).field_of_view(30.0)
+    renderer = Renderer.default().width(800).height(800).samples(128).camera(camera)
+    return scene, renderer
+
+
+def load_teapot_meshes(material):
+    """The four TriangleMeshes of scenes/teapot.yml (= tobj 1.0 output for teapot.obj's four `g` groups, with vertex
+    normals: 6 320 triangles), kept as the data fixture scenes/teapot_mesh.npz (scripts/make_fixtures.py)."""
+    d = np.load(os.path.join(SCENES_DIR, "teapot_mesh.npz"))
+    return [TriangleMesh.new(d[f"verts{i}"], d[f"indicies{i}"], d[f"normals{i}"], None, material)
+            for i in range(int(d["n_meshes"]))]
+
+
+def teapot():
+    """examples/teapot.rs:18-109 (= scenes/teapot.yml): smooth-normal meshes (mesh.rs:206-207), every mesh rotated by
+    `from_rotation_xz(90.)` (radians, as written).  1920x1080 @512, BVH."""
+    scene = Scene.new()
+    diffuse = scene.add_material(LambertianMat.new(ConstantTexture.new((0.2, 0.8, 0.3))))
+    for mesh in load_teapot_meshes(diffuse):
+        scene.add_object(RenderObject.new(mesh).rotate(Rotor3.from_rotation_xz(90.0)))
+    scene.set_environment(SkyEnv.default())
+    grey = scene.add_material(LambertianMat.with_color((0.5, 0.5, 0.5)))
+    scene.add_object(RenderObject.new(XZRect.new(-20.0, 20.0, -20.0, 20.0, 0.0, grey)))
+    light = scene.add_material(EmissiveMat.with_color((20.0, 20.0, 20.0)))
+    scene.add_object(RenderObject.new(YZRect.new(0.0, 4.0, 0.0, 4.0, -0.6, light))
+                     .rotate(Rotor3.from_rotation_xz(-30.0)).position(0.0, 4.0, 10.0))
+    camera = CameraSettings.default().cam_pos((1.0, 4.0, 8.0)).look_at((0.0, 1.0, 0.0)).field_of_view(40.0)
+    renderer = Renderer.default().width(1920).height(1080).samples(512).use_bvh(True).camera(camera)
     return scene, renderer
 
 

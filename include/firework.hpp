@@ -52,11 +52,16 @@ struct Rotor3 {
     static Rotor3 from_rotation_xz(float a) { return plane(a, 1); }
     static Rotor3 from_rotation_yz(float a) { return plane(a, 2); }
     Rotor3 operator*(const Rotor3 &b) const {   // geometric product on (1, e12, e13, e23)
+        // every sum is an fma chain (ultraviolet builds its products from mul_add): the association that reproduces the
+        // rotor serialised in the reference's scenes/conics.yml bit for bit (same chain as firework_amd/api.py)
         const Rotor3 &a = *this; Rotor3 r;
-        r.s = a.s * b.s - a.xy * b.xy - a.xz * b.xz - a.yz * b.yz;
-        r.xy = a.s * b.xy + a.xy * b.s - a.xz * b.yz + a.yz * b.xz;
-        r.xz = a.s * b.xz + a.xz * b.s + a.xy * b.yz - a.yz * b.xy;
-        r.yz = a.s * b.yz + a.yz * b.s - a.xy * b.xz + a.xz * b.xy;
+        auto chain = [](float x0, float y0, float x1, float y1, float x2, float y2, float x3, float y3) {
+            return std::fma(x0, y0, std::fma(x3, y3, std::fma(x2, y2, x1 * y1)));
+        };
+        r.s = chain(a.s, b.s, -a.xy, b.xy, -a.xz, b.xz, -a.yz, b.yz);
+        r.xy = chain(a.xy, b.s, a.s, b.xy, a.yz, b.xz, -a.xz, b.yz);
+        r.xz = chain(a.xz, b.s, a.s, b.xz, -a.yz, b.xy, a.xy, b.yz);
+        r.yz = chain(a.yz, b.s, a.s, b.yz, a.xz, b.xy, -a.xy, b.xz);
         return r;
     }
     static Rotor3 from_euler_angles(float roll, float pitch, float yaw) { return from_rotation_xz(yaw) * from_rotation_yz(pitch) * from_rotation_xy(roll); }

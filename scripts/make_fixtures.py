@@ -8,6 +8,13 @@
                                (cornell_box.png, suzanne.png, volume.png, ...): the only
                                reference-produced outputs that exist
   tests/golden/reference_yaml_pins.json <- rotor values found in scenes/*.yml
+  tests/golden/reference_png_lattice.npz <- every 2nd/4th/8th pixel of the reference's committed renders whose
+                               example still matches src/ (cornell_box, suzanne, volume, conics, Earth, teapot):
+                               the pixels tests/test_reference_renders.py renders with the oracle at the example's own
+                               resolution and spp (pixel_ids = the same lattice)
+  scenes/uvmap.png          <- /root/reference/uvmap.png           (ImageTexture of conics.rs / earth.rs)
+  scenes/teapot_mesh.npz    <- /root/reference/scenes/teapot.yml   (4 TriangleMeshes with vertex normals = tobj 1.0's
+                               output for teapot.obj; 6 320 triangles)
 
 Run in the build container only (/root/reference does not exist on the GPU box)."""
 import json
@@ -53,6 +60,34 @@ def main():
     }
     with open(f"{ROOT}/tests/golden/reference_png_stats.json", "w") as f:
         json.dump(stats, f, indent=1)
+
+    # lattice subsamples: (file, stride); pixel (y, x) with y % stride == x % stride == stride // 2
+    lat = {}
+    for name, stride in (("cornell_box.png", 2), ("suzanne.png", 4), ("volume.png", 4), ("conics.png", 4), ("Earth.png", 4),
+                         ("teapot.png", 8)):
+        im = np.asarray(Image.open(f"{REF}/{name}").convert("RGB"), np.uint8)
+        key = name.split(".")[0]
+        lat[key] = np.ascontiguousarray(im[stride // 2::stride, stride // 2::stride])
+        lat[key + "_meta"] = np.array([im.shape[1], im.shape[0], stride], np.int32)      # width, height, stride
+    np.savez_compressed(f"{ROOT}/tests/golden/reference_png_lattice.npz", **lat)
+    shutil.copyfile(f"{REF}/uvmap.png", f"{ROOT}/scenes/uvmap.png")
+
+    with open(f"{REF}/scenes/teapot.yml") as f:
+        y = yaml.load(f, Loader=getattr(yaml, "CSafeLoader", yaml.SafeLoader))
+    tp = {}
+    n = 0
+    for ro in y["render_objects"]:
+        m = ro["obj"]
+        if m["object_type"] != "TriangleMesh":
+            continue
+        tp[f"verts{n}"] = np.array([[v["x"], v["y"], v["z"]] for v in m["verts"]], np.float32)
+        tp[f"normals{n}"] = np.array([[v["x"], v["y"], v["z"]] for v in m["normals"]], np.float32)
+        tp[f"indicies{n}"] = np.array(m["indicies"], np.uint32)
+        assert m["uvs"] is None
+        n += 1
+    tp["n_meshes"] = np.array(n, np.int32)
+    np.savez_compressed(f"{ROOT}/scenes/teapot_mesh.npz", **tp)
+    print("teapot:", n, "meshes,", sum(tp[f"indicies{i}"].shape[0] // 3 for i in range(n)), "triangles")
 
     pins = []
     for sc in ("conics.yml", "suzanne.yml", "teapot.yml"):

@@ -126,7 +126,7 @@ def test_rotor_constructors_match_reference_yaml():
     ]
     for r, p in cases:
         for k in ("s", "xy", "xz", "yz"):
-            assert getattr(r, k) == pytest.approx(p[k], abs=2e-7), (k, r, p)
+            assert np.float32(getattr(r, k)) == np.float32(p[k]), (k, r, p)      # bit-equal in f32
     # signed zeros of the plane constructor (teapot.yml stores `xy: -0.0`)
     r = Rotor3.from_rotation_xz(90.0)
     assert math.copysign(1.0, r.xy) == -1.0 and math.copysign(1.0, r.yz) == -1.0
