@@ -2,19 +2,29 @@
 """bench.py — BASELINE.json's metric on BASELINE.json's config.
 
 metric : Mrays/s (+ Msamples/s and frame time) of cornell_box 512x512 @1024spp  (configs[1])
-step   : one full frame through the HIP wavefront path (scene already resident in HBM), tiles
-         sharded over the ranks, + the single gather of finished tiles to rank 0
-N>1    : launched by torch.distributed.run, one rank per GPU, RCCL (backend "nccl")
+step   : one full frame through the HIP wavefront path, tiles sharded over the ranks, + the single gather of the
+         finished tiles to rank 0.  TIMED REGION: the scene is already resident in HBM and the frame stays in HBM
+         (device-resident steady state); the region the reference itself times (main.rs:40-44: scene conversion + BVH
+         build + render, frame back on the host) is reported beside it as `one_shot`, never as `value`.
+N>1    : one rank per GPU over RCCL (backend "nccl").  `python bench.py --gpus N` starts its own N ranks (children of a
+         parent that never touches the GPU); under torch.distributed.run (WORLD_SIZE set) it is a rank itself.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     — dominant kernel's algorithmic HBM bytes / its HIP-event time vs the 8 TB/s peak
-  cpu_baseline — the CPU oracle (a C++ restatement of the reference's rayon loop; the Rust binary cannot
-                 be built in this image) timed on this host's cores on a bounded sample of the same scene
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline       — k_shade (the kernel that moves most HBM bytes): THIS layout's algorithmic bytes (fw_stats.bytes_shade,
+                   exact from the queue counters, elided zero deposits not counted) / its HIP-event time vs 8 TB/s;
+                   `traffic` = PMC bytes per launch from the committed rocprofv3 passes, only when they were taken from
+                   the same kernel sources as this build (else null)
+  roofline_frame — the whole frame: the layout's own bytes and SURVEY §8(d)'s generic 160 B/ray formula, both over device time
+  one_shot       — fw_render_scene: conversion + BVH build + upload + render + D2H (main.rs:40-44's region), median of 3
+  parity         — the same frame (or a pixel lattice of it, full spp) against the CPU oracle at the same seed
+  cpu_baseline   — the CPU oracle in the reference's sequential-LCG mode timed on this host's cores (bounded sample)
 """
 import argparse
-import glob
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,9 +32,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+KERNEL_SOURCES = ("firework_amd/csrc/fw_kernels.hip", "firework_amd/csrc/fw_runtime.cpp", "firework_amd/csrc/fw_device.h", "Makefile")
 
 
-def main():
+def kernel_source_sha():
+    """Identifies the build a profile under profiles/ was taken from (scripts/summarize_prof.py stores the same hash)."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -36,11 +56,37 @@ def main():
     ap.add_argument("--paths-per-batch", type=int, default=0)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--cpu-spp", type=int, default=0, help="spp of the bounded CPU-baseline sample")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and parity)")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-one-shot", action="store_true")
+    ap.add_argument("--parity-seconds", type=float, default=25.0, help="CPU budget of the parity leg (pixel lattice chosen to fit)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (=RCCL over xGMI) for real multi-GPU runs; gloo stages the gather through host memory and "
                          "lets several ranks share one GPU — a functional rehearsal of the N>1 path on a 1-GPU box")
-    args = ap.parse_args()
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N=1 only: initialise the process group and send the tiles through the gather anyway (exercises the RCCL call on one GPU)")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 writes the assembled u8 frame (H*W,3) to this .npy")
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as children BEFORE anything here touches the GPU
+    (this parent never imports torch), relay their output, return their exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     import numpy as np
     import torch
@@ -52,12 +98,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > n_dev:
+        raise SystemExit(f"{world} ranks but {n_dev} GPU(s) visible: RCCL needs one GPU per rank "
+                         f"(use --backend gloo to rehearse the N>1 path on fewer GPUs)")
     device_index = local_rank if args.backend == "nccl" else local_rank % max(1, n_dev)
-    if world > 1:
+    use_dist = world > 1 or args.force_collective
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(s.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(device_index)
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
@@ -70,8 +125,8 @@ def main():
     if not args.no_kernel_timing:
         renderer.time_kernels(True)
     s = renderer.settings
-    tr = TiledRenderer(scene, renderer, rank, world, device_index, dist=dist if world > 1 else None,
-                       host_staged_gather=(args.backend == "gloo"))
+    tr = TiledRenderer(scene, renderer, rank, world, device_index, dist=dist if use_dist else None,
+                       host_staged_gather=(args.backend == "gloo"), force_collective=args.force_collective)
 
     def barrier():
         if world > 1:
@@ -82,31 +137,38 @@ def main():
         tr.render_frame()
     barrier()
     t0 = time.perf_counter()
-    acc = {"rays": 0, "samples": 0, "ms_render": 0.0, "ms_extend": 0.0, "ms_shade": 0.0, "ms_raygen": 0.0,
-           "ms_accumulate": 0.0, "n_extend_launches": 0}
+    keys = ("rays", "samples", "ms_render", "ms_extend", "ms_shade", "ms_raygen", "ms_accumulate", "n_extend_launches",
+            "n_shade_launches", "bytes_raygen", "bytes_extend", "bytes_shade", "bytes_accumulate", "algorithmic_bytes")
+    acc = {k: 0 for k in keys}
+    ms_gather = 0.0
     for _ in range(args.steps):
         tr.render_frame()
         for k in acc:
             acc[k] += tr.last_stats[k]
+        ms_gather += tr.last_ms_gather
     barrier()
     elapsed = time.perf_counter() - t0
 
     # max over ranks of the elapsed time; sums over ranks of the work counters
-    vec = torch.tensor([elapsed, acc["rays"], acc["samples"], acc["ms_extend"], acc["ms_shade"], acc["ms_render"]],
+    vec = torch.tensor([elapsed, acc["rays"], acc["samples"], acc["ms_extend"], acc["ms_shade"], acc["ms_render"], ms_gather],
                        dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         mx = vec.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         elapsed = float(mx[0])
+        ms_gather = float(mx[6])
     total_rays, total_samples = float(vec[1]), float(vec[2])
 
     if rank == 0:
         frame = tr.frame.cpu().numpy()
-        assert frame.shape == (s["width"] * s["height"], 3) and frame.any()
+        assert frame.shape == (s["width"] * s["height"], 3)
+        if args.dump_frame:
+            np.save(args.dump_frame, frame)
         ms_step = elapsed * 1e3 / args.steps
+        headline = args.config == "C2_cornell_box" and not (args.width or args.height or args.spp)
         out = {
-            "metric": "Mrays/s, cornell_box 512x512 @1024spp (whole frame incl. tile gather)" if args.config == "C2_cornell_box" and not (args.width or args.spp) else f"Mrays/s, {args.config}",
+            "metric": "Mrays/s, cornell_box 512x512 @1024spp (scene resident in HBM; whole frame incl. tile gather)" if headline else f"Mrays/s, {args.config}",
             "value": total_rays / elapsed / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -117,70 +179,158 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.config} {s['width']}x{s['height']} @{s['samples']}spp", "use_bvh": bool(s["use_bvh"]),
-                       "tiles": "16x16, dealt diagonally over ranks", "collective": f"one gather of u8 tiles to rank 0 ({args.backend})" if world > 1 else "none",
+                       "tiles": "16x16, dealt diagonally over ranks",
+                       "collective": (f"one gather of u8 tiles to rank 0 ({args.backend}, world_size {dist.get_world_size()})" if use_dist else "none"),
                        "rng": "counter (pcg4d) keyed by (seed,pixel,sample,dimension)", "seed": s["seed"]},
+            "timed_region": "device-resident steady state: scene already in HBM, frame assembled in HBM on rank 0 "
+                            "(the reference's own region, main.rs:40-44, is `one_shot`)",
             "msamples_per_s": total_samples / elapsed / 1e6,
             "frame_time_ms": ms_step,
             "rays_per_sample": total_rays / max(1.0, total_samples),
+            "ms_gather_per_step": ms_gather / args.steps,
         }
         if not args.no_kernel_timing:
-            # rank-0 kernel classes (every rank runs the same kernels on 1/N of the pixels).
-            # Algorithmic HBM bytes of THIS implementation's layout, exact from the counters:
-            #   k_extend: reads ray 24 B, writes hit 8 B                          -> 32 B per ray
-            #   k_shade : reads ray 24 + hit 8 + state 16; writes ray 24 + state 16 per continuing path,
-            #             radiance 16 per terminated path                        -> 88*rays - 24*samples
-            # (SURVEY §8d's generic figure is 40 + 120 = 160 B/ray; this layout moves fewer bytes.)
-            rays0, samples0 = acc["rays"], acc["samples"]
-            ext_bytes = 32.0 * rays0
-            shd_bytes = 88.0 * rays0 - 24.0 * samples0
-            ext_s, shd_s = acc["ms_extend"] / 1e3, acc["ms_shade"] / 1e3
-            # the roofline kernel is the one that moves the most HBM bytes (k_shade: 104 of the frame's 160 GB); k_extend takes
-            # about as long but is bound by VALU instruction issue, so an HBM fraction says nothing about it —
-            # it is reported under "other_kernel".  (Picking the longer of the two made the object flip between boxes.)
-            dom = "k_shade" if shd_s > 0 else "k_extend"
-            b, t = (ext_bytes, ext_s) if dom == "k_extend" else (shd_bytes, shd_s)
-            ach = b / t / 1e9 if t > 0 else 0.0
-            launches = max(1, acc["n_extend_launches"])
-            traffic, traffic_src = None, None
-            pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-            if pmcs:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-                try:
-                    pk = json.load(open(pmcs[-1]))["kernels"]
-                    key = [k for k in pk if dom in k][0]
-                    traffic, traffic_src = pk[key]["hbm_bytes_per_launch"], os.path.relpath(pmcs[-1], ROOT)
-                except Exception:
-                    pass
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                               "algorithmic_bytes_per_launch": b / launches,
-                               "avg_launch_us": t * 1e6 / launches,
-                               "bytes_per_ray": b / max(1.0, rays0),
-                               "other_kernel": {"kernel": "k_shade" if dom == "k_extend" else "k_extend", "bound": "hbm" if dom == "k_extend" else "valu_issue",
-                                                "ms_per_step": (acc["ms_shade"] if dom == "k_extend" else acc["ms_extend"]) / args.steps,
-                                                "achieved": ((shd_bytes / shd_s) if dom == "k_extend" else (ext_bytes / ext_s)) / 1e9 if min(ext_s, shd_s) > 0 else 0.0}}
-            frame_bytes = 160.0 * rays0 + 24.0 * acc["samples"]
-            out["roofline_frame"] = {"achieved": frame_bytes / (acc["ms_render"] / 1e3) / 1e9, "unit": "GB/s",
-                                     "frac": frame_bytes / (acc["ms_render"] / 1e3) / 1e9 / HBM_PEAK_GBS,
-                                     "formula": "160*rays + 24*samples over device time"}
-            out["kernel_ms_per_step"] = {k: acc[k] / args.steps for k in ("ms_render", "ms_raygen", "ms_extend", "ms_shade", "ms_accumulate")}
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import oracle_binding as ob       # CPU oracle: the checker, timed as the reported baseline
-            from firework_amd._abi import FW_RNG_LCG
+            out.update(roofline_objects(acc, args, tr, renderer))
+        if world == 1 and not args.no_one_shot:
+            out["one_shot"] = one_shot(scene, renderer, device_index)
+        if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            # bounded sample: ~15 s of CPU work at ~0.55 Msamples/s per core on this scene
-            cpu_spp = args.cpu_spp or max(16, min(s["samples"], int(15.0 * 0.55e6 * cores / (s["width"] * s["height"]))))
-            cscene, cr = scenes.config(args.config, args.width, args.height, cpu_spp)
-            c0 = time.perf_counter()
-            cres = ob.render(cscene, cr, rng_mode=FW_RNG_LCG, n_threads=cores)   # reference semantics: per-pixel sequential LCG
-            cdt = time.perf_counter() - c0
-            out["cpu_baseline"] = {"value": cres.stats["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-                                   "msamples_per_s": cres.stats["samples"] / cdt / 1e6,
-                                   "sample": f"{args.config} {cr.settings['width']}x{cr.settings['height']} @{cpu_spp}spp "
-                                             f"({cres.stats['samples']} samples, {cdt:.1f} s; cost is linear in spp)"}
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(args, s, cores)
+            if not args.no_parity:
+                out["parity"] = parity(args, tr, renderer, scene, frame, out["cpu_baseline"], cores)
+        print(json.dumps(out), flush=True)
     tr.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+
+
+def roofline_objects(acc, args, tr, renderer):
+    """Rank-0 kernel classes (every rank runs the same kernels on 1/N of the pixels).  Bytes: fw_stats.bytes_* = this
+    layout's own algorithmic HBM bytes per kernel class, exact from the queue counters (fw_runtime.cpp, DESIGN.md §5);
+    the deposits that k_shade elides over a black environment are counted by one extra untimed frame."""
+    import glob
+    res = {}
+    steps = args.steps
+    exact = tr.scene.render(renderer.count_deposits(True), pixel_ids=tr.tg.ids, out_device_ptrs=(tr.tg.local.data_ptr(), None, None))
+    renderer.count_deposits(False)
+    shd_bytes, ext_bytes = float(exact["bytes_shade"]), float(exact["bytes_extend"])       # per frame
+    shd_s, ext_s = acc["ms_shade"] / 1e3 / steps, acc["ms_extend"] / 1e3 / steps
+    n_sh = max(1, acc["n_shade_launches"] // steps)
+    n_ex = max(1, acc["n_extend_launches"] // steps)
+    sha = kernel_source_sha()
+    traffic = traffic_src = frac_traffic = None
+    other_bound = other_src = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("source_sha") != sha or d.get("workload") != f"{args.config} {renderer.settings['width']}x{renderer.settings['height']} @{renderer.settings['samples']}spp":
+                continue
+            k = [k for k in d["kernels"] if "k_shade" in k][0]
+            traffic, traffic_src = d["kernels"][k]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+            break
+        except Exception:
+            continue
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            if d.get("source_sha") != sha:
+                continue
+            k = [k for k in d["kernels"] if "k_extend" in k][0]
+            other_bound, other_src = d["kernels"][k]["bound"], os.path.relpath(path, ROOT)
+            break
+        except Exception:
+            continue
+    ach = shd_bytes / shd_s / 1e9 if shd_s > 0 else 0.0
+    if traffic is not None and shd_s > 0:
+        frac_traffic = traffic * n_sh / shd_s / 1e9 / HBM_PEAK_GBS
+    res["roofline"] = {
+        "bound": "hbm", "kernel": "k_shade", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_source": traffic_src, "frac_traffic": frac_traffic,
+        "algorithmic_bytes_per_launch": shd_bytes / n_sh, "avg_launch_us": shd_s * 1e6 / n_sh,
+        "bytes_per_ray": shd_bytes / max(1.0, float(exact["rays"])),
+        "bytes": "this layout's streams, exact from the queue counters; zero deposits elided over a black environment are not counted "
+                 f"({exact['deposits']} of {exact['samples']} radiance records written)",
+        "other_kernel": {"kernel": "k_extend", "bound": other_bound, "bound_source": other_src,
+                         "ms_per_step": ext_s * 1e3, "achieved": ext_bytes / ext_s / 1e9 if ext_s > 0 else 0.0,
+                         "frac_hbm": ext_bytes / ext_s / 1e9 / HBM_PEAK_GBS if ext_s > 0 else 0.0,
+                         "algorithmic_bytes_per_launch": ext_bytes / n_ex, "avg_launch_us": ext_s * 1e6 / n_ex},
+    }
+    dev_s = acc["ms_render"] / 1e3 / steps
+    layout = float(exact["bytes_raygen"] + exact["bytes_extend"] + exact["bytes_shade"] + exact["bytes_accumulate"])
+    survey = float(exact["algorithmic_bytes"])
+    res["roofline_frame"] = {"unit": "GB/s", "device_ms": dev_s * 1e3,
+                             "layout": {"bytes": layout, "achieved": layout / dev_s / 1e9, "frac": layout / dev_s / 1e9 / HBM_PEAK_GBS,
+                                        "formula": "bytes_raygen + bytes_extend + bytes_shade + bytes_accumulate (fw_stats) over device time"},
+                             "survey": {"bytes": survey, "achieved": survey / dev_s / 1e9, "frac": survey / dev_s / 1e9 / HBM_PEAK_GBS,
+                                        "formula": "160*rays + 24*samples (SURVEY §8d, a generic split-kernel layout) over device time"}}
+    res["kernel_ms_per_step"] = {k: acc[k] / steps for k in ("ms_render", "ms_raygen", "ms_extend", "ms_shade", "ms_accumulate")}
+    return res
+
+
+def one_shot(scene, renderer, device_index):
+    """The region the reference times (main.rs:40-44): Scene -> SceneInternal + BVH build (+ upload) + render + the frame
+    back in host memory, through fw_render_scene.  Median of three calls after one warm call (the path pools stay cached
+    per device between calls, like any allocator would keep them)."""
+    from firework_amd import _lib
+    sd = scene.to_desc()
+    runs = []
+    for rep in range(4):
+        t0 = time.perf_counter()
+        res = _lib.render_scene(sd, renderer, device=device_index)
+        wall = (time.perf_counter() - t0) * 1e3
+        st = res.stats
+        runs.append({"ms_wall": st["ms_wall"], "ms_wall_incl_binding": wall, "ms_scene": st["ms_scene"], "ms_render": st["ms_render"],
+                     "ms_d2h": st["ms_d2h"], "mrays_per_s": st["rays"] / st["ms_wall"] / 1e3})
+    runs = sorted(runs[1:], key=lambda r: r["ms_wall"])
+    med = dict(runs[1])
+    med["ms_wall_all"] = [round(r["ms_wall"], 2) for r in runs]
+    med["region"] = "fw_render_scene: flatten + BVH build + upload + render + D2H of rgb8/gamma/linear frames (PCIe-inclusive)"
+    return med
+
+
+def cpu_baseline(args, s, cores):
+    from firework_amd import scenes
+    from firework_amd._abi import FW_RNG_LCG
+    from oracle import oracle_binding as ob       # CPU oracle: the checker, timed as the reported baseline
+    # bounded sample: ~15 s of CPU work at ~0.55 Msamples/s per core on this scene
+    cpu_spp = args.cpu_spp or max(16, min(s["samples"], int(15.0 * 0.55e6 * cores / (s["width"] * s["height"]))))
+    cscene, cr = scenes.config(args.config, args.width, args.height, cpu_spp)
+    c0 = time.perf_counter()
+    cres = ob.render(cscene, cr, rng_mode=FW_RNG_LCG, n_threads=cores)   # reference semantics: per-pixel sequential LCG
+    cdt = time.perf_counter() - c0
+    return {"value": cres.stats["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "msamples_per_s": cres.stats["samples"] / cdt / 1e6,
+            "timed_region": "scene conversion + BVH build + render (main.rs:40-44), C++ restatement of the reference's rayon loop",
+            "sample": f"{args.config} {cr.settings['width']}x{cr.settings['height']} @{cpu_spp}spp "
+                      f"({cres.stats['samples']} samples, {cdt:.1f} s; cost is linear in spp)"}
+
+
+def parity(args, tr, renderer, scene, frame_u8, cpu, cores):
+    """north_star's gate where it is defined: per-pixel RGB of the bench config, GPU vs the CPU oracle at the same seed
+    (counter RNG), RMS on the post-gamma clamped floats (render.rs:184-190).  All pixels when the CPU budget allows,
+    otherwise every k-th pixel in x and y at the full sample count."""
+    import numpy as np
+    from oracle import oracle_binding as ob
+    s = renderer.settings
+    w, h, spp = s["width"], s["height"], s["samples"]
+    est = w * h * spp / max(1e-9, cpu["msamples_per_s"] * 1e6)          # seconds for every pixel at the measured CPU rate
+    stride = 1
+    while est / (stride * stride) > args.parity_seconds:
+        stride += 1
+    ys, xs = np.meshgrid(np.arange(stride // 2, h, stride), np.arange(stride // 2, w, stride), indexing="ij")
+    ids = (ys * w + xs).reshape(-1).astype(np.uint32)
+    g = tr.scene.render(renderer, pixel_ids=ids)                          # HIP path, host buffers, same pixels
+    t0 = time.perf_counter()
+    c = ob.render(scene, renderer, pixel_ids=ids, n_threads=cores)
+    dt = time.perf_counter() - t0
+    rms = float(np.sqrt(np.mean((g.gamma.astype(np.float64) - c.gamma) ** 2)))
+    rms_lin = float(np.sqrt(np.mean((g.linear.astype(np.float64) - c.linear) ** 2)))
+    return {"rms_gamma": rms, "rms_linear": rms_lin, "gate": 1e-3, "pass": bool(rms <= 1e-3),
+            "u8_diffs": int((g.rgb8 != c.rgb8).sum()), "u8_values": int(c.rgb8.size),
+            "rays_equal": bool(g.stats["rays"] == c.stats["rays"]), "rays": int(g.stats["rays"]),
+            "timed_frame_equals_checked_frame": bool(np.array_equal(frame_u8[ids], g.rgb8)),
+            "pixels": int(ids.shape[0]), "pixel_stride": stride, "spp": spp, "oracle_seconds": round(dt, 1),
+            "what": f"{args.config} {w}x{h} @{spp}spp, every {stride}th pixel in x and y, GPU vs CPU oracle (FW_RNG_CTR, same seed)"}
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 """ctypes mirror of include/firework_hip.h (the C ABI).  Field order and types must match the header."""
 import ctypes as C
 
-FW_ABI_VERSION = 3
+FW_ABI_VERSION = 4
 FW_MAX_SEGMENTS = 11
 
 # fw_status
@@ -25,6 +25,7 @@ FW_MAT_LAMBERTIAN, FW_MAT_METAL, FW_MAT_DIELECTRIC, FW_MAT_EMISSIVE, FW_MAT_ISOT
 FW_ENV_COLOR, FW_ENV_SKY, FW_ENV_HDR = range(3)
 FW_RNG_CTR, FW_RNG_LCG = 0, 1
 FW_FLAG_TIME_KERNELS = 1
+FW_FLAG_COUNT_DEPOSITS = 2
 
 f32, i32, u32, u64 = C.c_float, C.c_int32, C.c_uint32, C.c_uint64
 
@@ -89,7 +90,9 @@ class fw_stats(C.Structure):
                 ("ms_raygen", C.c_double), ("ms_extend", C.c_double), ("ms_shade", C.c_double),
                 ("ms_accumulate", C.c_double),
                 ("n_extend_launches", u32), ("n_shade_launches", u32), ("n_batches", u32),
-                ("tlas_nodes", u32), ("blas_nodes", u32), ("reserved", u32)]
+                ("tlas_nodes", u32), ("blas_nodes", u32), ("reserved", u32),
+                ("bytes_raygen", u64), ("bytes_extend", u64), ("bytes_shade", u64), ("bytes_accumulate", u64),
+                ("deposits", u64), ("parked_rays", u64), ("ms_wall", C.c_double), ("ms_d2h", C.c_double)]
 
     def as_dict(self):
         d = {}

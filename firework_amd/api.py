@@ -588,7 +588,11 @@ class SceneDesc:
 
         shapes: List[A.fw_shape] = []
 
+        shape_index = {}      # one fw_shape per Python shape object: objects that share a TriangleMesh share its BLAS
+
         def add_shape(s: Shape) -> int:
+            if id(s) in shape_index:
+                return shape_index[id(s)]
             fs = A.fw_shape()
             fs.inner = -1
             if isinstance(s, Sphere):
@@ -625,6 +629,7 @@ class SceneDesc:
             else:
                 raise TypeError(f"unknown shape {type(s).__name__}")
             shapes.append(fs)
+            shape_index[id(s)] = len(shapes) - 1
             return len(shapes) - 1
 
         objs = []
@@ -667,6 +672,34 @@ class SceneDesc:
 
     def ptr(self):
         return C.byref(self.desc)
+
+    def content_hash(self) -> str:
+        """sha256 over everything a render depends on: every struct field that is not a pointer, and the arrays the
+        pointers name (vertices, indices, normals, uvs, image and HDR pixels).  Identifies a scene in a checkpoint."""
+        import hashlib
+        h = hashlib.sha256()
+
+        def feed(obj):
+            for name, _ in obj._fields_:
+                v = getattr(obj, name)
+                if isinstance(v, C.Structure):
+                    feed(v)
+                elif isinstance(v, C._Pointer):
+                    continue
+                elif isinstance(v, C.Array):
+                    h.update(bytes(v))
+                else:
+                    h.update(repr(v).encode())
+        d = self.desc
+        for arr, n in ((self.objects, d.n_objects), (self.shapes, d.n_shapes), (self.materials, d.n_materials), (self.textures, d.n_textures)):
+            for i in range(n):
+                feed(arr[i])
+        feed(d.environment)
+        for a in self._keep:
+            if isinstance(a, np.ndarray):
+                h.update(str(a.shape).encode())
+                h.update(np.ascontiguousarray(a).tobytes())
+        return h.hexdigest()
 
 
 # --------------------------------------------------------------------------- camera / renderer
@@ -778,6 +811,12 @@ class Renderer:
             self.settings["flags"] & ~A.FW_FLAG_TIME_KERNELS)
         return self
 
+    def count_deposits(self, on=True):
+        """FW_FLAG_COUNT_DEPOSITS: fw_stats.deposits / bytes_shade become exact where zero deposits are elided (one extra pass)."""
+        self.settings["flags"] = (self.settings["flags"] | A.FW_FLAG_COUNT_DEPOSITS) if on else (
+            self.settings["flags"] & ~A.FW_FLAG_COUNT_DEPOSITS)
+        return self
+
     def to_params(self, pixel_ids: Optional[np.ndarray] = None, rng_mode: int = A.FW_RNG_CTR) -> A.fw_render_params:
         s = self.settings
         p = A.fw_render_params()
@@ -813,13 +852,28 @@ class Renderer:
         total, n = int(s["samples"]), int(s["width"]) * int(s["height"])
         passes = max(1, min(int(passes), total))
         accum, done = np.zeros((n, 4), np.float32), 0
-        tag = np.array([s["width"], s["height"], s["seed"] & 0xffffffff, s["seed"] >> 32], dtype=np.int64)
-        if checkpoint:
-            import os
-            if os.path.exists(checkpoint):
-                ck = np.load(checkpoint)
-                if ck["accum"].shape == accum.shape and np.array_equal(ck["tag"], tag) and 0 < int(ck["done"]) <= total:
-                    accum, done = np.ascontiguousarray(ck["accum"], dtype=np.float32), int(ck["done"])
+        # what the accumulated sums depend on: image size, seed, the scene's content, the camera and use_bvh (the hit of a
+        # ray that grazes a padded box can differ between the linear scan and the BVH, as in the reference).  gamma and the
+        # total sample count do not enter the sums.
+        import hashlib
+        import os
+        import sys
+        cam = self._camera.to_abi()
+        tag = hashlib.sha256(repr((int(s["width"]), int(s["height"]), int(s["seed"]), bool(s["use_bvh"]), sd.content_hash(),
+                                   bytes(cam))).encode()).hexdigest()
+        if checkpoint and not str(checkpoint).endswith(".npz"):
+            checkpoint = str(checkpoint) + ".npz"                       # the name np.savez would write
+        if checkpoint and os.path.exists(checkpoint):
+            try:
+                with np.load(checkpoint) as ck:
+                    ok = ck["accum"].shape == accum.shape and str(ck["tag"]) == tag and 0 < int(ck["done"]) <= total
+                    if ok:
+                        accum, done = np.ascontiguousarray(ck["accum"], dtype=np.float32), int(ck["done"])
+                    else:
+                        print(f"checkpoint {checkpoint}: written for another scene, camera, size, seed or use_bvh "
+                              f"(or holds more samples than asked for) - ignored, starting from sample 0", file=sys.stderr)
+            except Exception as e:                                      # truncated or foreign file
+                print(f"checkpoint {checkpoint}: unreadable ({type(e).__name__}: {e}) - ignored, starting from sample 0", file=sys.stderr)
         ds = _lib.DeviceScene(sd, device)
         try:
             bounds = [round(total * k / passes) for k in range(passes + 1)]
@@ -830,8 +884,11 @@ class Renderer:
                 r = copy.copy(self); r.settings = dict(self.settings); r.settings["samples"] = hi - lo
                 res = ds.render_progressive(r, lo, accum)
                 done = hi
-                if checkpoint:
-                    np.savez(checkpoint, accum=accum, done=np.int64(done), tag=tag)
+                if checkpoint:                                          # atomic: a kill during the write leaves the old file
+                    tmp = f"{checkpoint}.tmp.{os.getpid()}"
+                    with open(tmp, "wb") as f:
+                        np.savez(f, accum=accum, done=np.int64(done), tag=np.array(tag))
+                    os.replace(tmp, checkpoint)
                 yield res
         finally:
             ds.close()

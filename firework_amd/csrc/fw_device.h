@@ -98,7 +98,9 @@ struct DCamera {   // camera.rs:7-16
 struct DFrame {
     uint32_t width, height;
     uint32_t n_pixels;            // pixels this call renders
-    const uint32_t *pixel_ids;    // device copy of fw_render_params.pixel_ids, or nullptr
+    const uint32_t *pixel_ids;    // device copy of fw_render_params.pixel_ids (or the library's own tile order, below), or nullptr
+    uint32_t scatter_out;         // pixel_ids is the library's own 16x16-tile order of a whole frame: k_resolve writes pixel
+                                  // pixel_ids[p] at output index pixel_ids[p] (the caller sees index order)
     uint32_t seed32;
     uint32_t sample0;             // first sample index of this batch
     uint32_t spp_batch;           // samples per pixel in this batch
@@ -131,11 +133,16 @@ struct DQueue {
 struct DPark {
     float4 *ray_a; float2 *ray_b; float4 *meta;
     uint32_t *pcount;
+    uint32_t *ptotal;   // per wave: parked rays over all segments of the batch (statistics; zeroed per batch)
 };
+
+// Bytes per record of the streams above: what fw_stats.bytes_* (the layout's own algorithmic HBM bytes) are computed from,
+// kept next to the layout so that the two change together.
+constexpr uint32_t B_RAY = 24, B_RAY_PINHOLE0 = 16, B_STATE = 16, B_HIT = 8, B_DEPOSIT = 16, B_PARK = 40, B_ACCUM = 16;
 
 constexpr uint32_t MISS = 0xffffffffu;
 constexpr int MAX_SEGMENTS = 11;
-constexpr int COUNT_STRIDE = 16;  // u32 counters per batch: [0..10] queue sizes, [11] spare
+constexpr int COUNT_STRIDE = 16;  // u32 counters per batch: [0..10] queue sizes, [11] parked rays, [12] deposits written (FW_FLAG_COUNT_DEPOSITS)
 
 // launch wrappers (fw_kernels.hip)
 struct LaunchCfg {
@@ -156,7 +163,10 @@ void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, 
                   float4 *sample_rad, int segment);
 void launch_bounce(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, float4 *sample_rad, int segment,
                    bool use_bvh);
-void launch_queue_totals(const LaunchCfg &, uint32_t *totals);
+void launch_queue_totals(const LaunchCfg &, uint32_t *totals, const uint32_t *ptotal);
+void launch_tile_order(hipStream_t stream, uint32_t width, uint32_t height, uint32_t *ids);
+void launch_upload(hipStream_t stream, const void *pinned_src, void *dst, size_t bytes);
+void launch_count_deposits(const LaunchCfg &, const float4 *sample_rad, uint32_t n_slots, uint32_t *total);
 void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out);
 void launch_accumulate(const LaunchCfg &, const DFrame &, const float4 *sample_rad, float4 *accum);
 void launch_resolve(const LaunchCfg &, const DFrame &, const float4 *accum, uint32_t total_spp, float gamma,

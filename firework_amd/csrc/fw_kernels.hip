@@ -1112,6 +1112,7 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
     if (w >= q.n_waves) return;
     TS_BEGIN();
     const uint32_t n = park.pcount[w];
+    if (lane == 0 && n) park.ptotal[w] += n;                         // statistics (fw_stats.parked_rays): wave-private, no atomics
     const uint32_t base = w * q.cap;
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     float4 ca = make_float4(0, 0, 0, 0), na = ca, cm = ca, nm = ca; float2 cb = make_float2(0, 0), nb = cb;
@@ -1584,16 +1585,33 @@ __global__ __launch_bounds__(WB) void k_bounce(DScene sc, DFrame f, DPaths in, D
     if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
 }
 
-// per-segment queue totals of one batch (ray statistics): totals[s] += sum_w wcount[s][w]; grid = (slices, segments)
-__global__ __launch_bounds__(BLOCK) void k_queue_totals(DQueue q, uint32_t *totals) {
+// per-segment queue totals of one batch (ray statistics): totals[s] += sum_w wcount[s][w]; grid = (slices, segments + 1);
+// the last row sums the waves' parked-ray counts (ptotal, may be null) into totals[MAX_SEGMENTS]
+__global__ __launch_bounds__(BLOCK) void k_queue_totals(DQueue q, uint32_t *totals, const uint32_t *ptotal) {
     __shared__ uint32_t part[BLOCK];
     const uint32_t seg = blockIdx.y;
+    if (seg == (uint32_t)MAX_SEGMENTS && !ptotal) return;
+    const uint32_t *src = seg == (uint32_t)MAX_SEGMENTS ? ptotal : q.wcount + (size_t)seg * q.n_waves;
     uint32_t acc = 0;
-    for (uint32_t w = blockIdx.x * BLOCK + threadIdx.x; w < q.n_waves; w += gridDim.x * BLOCK) acc += q.wcount[(size_t)seg * q.n_waves + w];
+    for (uint32_t w = blockIdx.x * BLOCK + threadIdx.x; w < q.n_waves; w += gridDim.x * BLOCK) acc += src[w];
     part[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s2 = BLOCK / 2; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2]; __syncthreads(); }
     if (threadIdx.x == 0 && part[0]) atomicAdd(&totals[seg], part[0]);
+}
+// FW_FLAG_COUNT_DEPOSITS: how many radiance records k_shade wrote in this batch.  Over a black environment k_raygen zeroes
+// every record and k_shade elides the zeros, so the records that are not all-zero are exactly the ones written.
+__global__ __launch_bounds__(BLOCK) void k_count_deposits(const float4 *__restrict__ sample_rad, uint32_t n_slots, uint32_t *total) {
+    __shared__ uint32_t part[BLOCK];
+    uint32_t acc = 0;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_slots; i += gridDim.x * BLOCK) {
+        const float4 v = sample_rad[i];
+        acc += (v.x != 0.f || v.y != 0.f || v.z != 0.f) ? 1u : 0u;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (uint32_t s2 = BLOCK / 2; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2]; __syncthreads(); }
+    if (threadIdx.x == 0 && part[0]) atomicAdd(total, part[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1633,12 +1651,45 @@ __global__ __launch_bounds__(WB) void k_accumulate(DFrame f, const float4 *__res
     }
 }
 
+// A whole frame is traced in 16x16-tile order, not row order: the 64 paths of a chunk are then a 16x4 block of pixels whose
+// camera rays hit the same objects (k_extend_linear's segment-0 box pre-test skips more, every kernel diverges less):
+// cornell 512x512@1024 51 -> 45 ms against 64 consecutive pixels of one row.  ids[i] = the i-th pixel in that order
+// (tiles row-major, pixels row-major inside a tile; the last tile row / column may be narrower).
+constexpr uint32_t TILE = 16;
+__global__ __launch_bounds__(BLOCK) void k_tile_order(uint32_t W, uint32_t H, uint32_t *__restrict__ ids) {
+    const uint32_t n = W * H, tx = (W + TILE - 1) / TILE;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t r = i / (W * TILE), j = i - r * W * TILE;           // tile row; offset inside it
+        const uint32_t hr = min(TILE, H - r * TILE);                        // its height
+        const uint32_t c = min(j / (TILE * hr), tx - 1u), k = j - c * TILE * hr;
+        const uint32_t wc = min(TILE, W - c * TILE);                        // the tile's width
+        const uint32_t y = k / wc, x = k - y * wc;
+        ids[i] = (r * TILE + y) * W + c * TILE + x;
+    }
+}
+void launch_tile_order(hipStream_t stream, uint32_t width, uint32_t height, uint32_t *ids) {
+    const uint32_t n = width * height;
+    hipLaunchKernelGGL(k_tile_order, dim3(std::min<uint32_t>((n + BLOCK - 1) / BLOCK, 4096u)), dim3(BLOCK), 0, stream, width, height, ids);
+}
+// Scene upload: a kernel reads the staging blob from pinned host memory.  The copy engines are kept out of the one-shot path:
+// a 2.5 KB hipMemcpy(Async) + stream synchronisation there stalled for 10-30 ms every few calls (tools/oneshot.py with
+// FIREWORK_TRACE=1), and a kernel is stream-ordered with the render that follows, so nothing has to wait on the host.
+__global__ __launch_bounds__(BLOCK) void k_upload(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * BLOCK) dst[i] = src[i];
+}
+void launch_upload(hipStream_t stream, const void *pinned_src, void *dst, size_t bytes) {
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_upload, dim3((unsigned)std::min<size_t>((n16 + BLOCK - 1) / BLOCK, 8192)), dim3(BLOCK), 0, stream,
+                       (const uint4 *)pinned_src, (uint4 *)dst, n16);
+}
+
 __device__ __forceinline__ uint8_t sat_u8(float f) { if (!(f > 0.f)) return 0; if (f >= 255.f) return 255; return (uint8_t)f; }
 
 __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame f, const float4 *__restrict__ accum, uint32_t total_spp, float gamma,
                                                    uint8_t *rgb8, float *gamma_rgb, float *linear_rgb) {
-    for (uint32_t p = blockIdx.x * BLOCK + threadIdx.x; p < f.n_pixels; p += gridDim.x * BLOCK) {
-        float4 a = accum[p];
+    for (uint32_t q = blockIdx.x * BLOCK + threadIdx.x; q < f.n_pixels; q += gridDim.x * BLOCK) {
+        float4 a = accum[q];
+        const uint32_t p = f.scatter_out ? f.pixel_ids[q] : q;                       // output index (the library's tile order is undone here)
         V3 total = mk(a.x, a.y, a.z) / (float)total_spp;                             // render.rs:184
         float ig = fdiv(1.f, gamma);
         V3 g = mk(powf(total.x, ig), powf(total.y, ig), powf(total.z, ig));           // render.rs:186
@@ -1732,8 +1783,11 @@ extern "C" int fw_debug_trav_stats(unsigned long long out[8]) {   // debug build
     return hipMemcpyToSymbol(HIP_SYMBOL(g_trav), zero, sizeof zero) == hipSuccess ? 0 : -1;
 }
 #endif
-void launch_queue_totals(const LaunchCfg &c, uint32_t *totals) {
-    hipLaunchKernelGGL(k_queue_totals, dim3(32, MAX_SEGMENTS), dim3(BLOCK), 0, c.stream, c.q, totals);   // totals are zeroed per frame
+void launch_queue_totals(const LaunchCfg &c, uint32_t *totals, const uint32_t *ptotal) {
+    hipLaunchKernelGGL(k_queue_totals, dim3(32, MAX_SEGMENTS + 1), dim3(BLOCK), 0, c.stream, c.q, totals, ptotal);   // totals are zeroed per frame
+}
+void launch_count_deposits(const LaunchCfg &c, const float4 *sample_rad, uint32_t n_slots, uint32_t *total) {
+    hipLaunchKernelGGL(k_count_deposits, dim3(2048), dim3(BLOCK), 0, c.stream, sample_rad, n_slots, total);
 }
 void launch_accumulate(const LaunchCfg &c, const DFrame &f, const float4 *sample_rad, float4 *accum) {
     uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)f.n_pixels + WB - 1) / WB, 65536));

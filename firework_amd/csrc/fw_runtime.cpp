@@ -284,7 +284,17 @@ struct Workspace {
     DevBuf accum, totals, pixel_ids, out_rgb8, out_gamma, out_linear;
     DevBuf scene_cache;                   // the last destroyed scene's allocation, reused by the next fw_scene_create
     std::vector<hipEvent_t> events;       // [0] frame start, [1] frame stop, [2] fork, [3..] per-batch "accumulated" events
+    hipEvent_t ev_d2h = nullptr;          // after the device -> host copies of the outputs
+    DevBuf tile_ids; uint32_t tile_w = 0, tile_h = 0;   // the library's own 16x16-tile pixel order of a (tile_w x tile_h) frame
+    void *staging = nullptr; size_t staging_bytes = 0;  // pinned host memory the scene blob is assembled in (k_upload reads it)
+    void *host_out = nullptr; size_t host_out_bytes = 0; // pinned host memory the counters and output frames are copied into
+    hipEvent_t ev_upload = nullptr;       // after the latest scene upload on this device: renders wait for it in stream order
     void release() {
+        if (ev_d2h) { (void)hipEventDestroy(ev_d2h); ev_d2h = nullptr; }
+        if (ev_upload) { (void)hipEventSynchronize(ev_upload); (void)hipEventDestroy(ev_upload); ev_upload = nullptr; }
+        if (staging) { (void)hipHostFree(staging); staging = nullptr; staging_bytes = 0; }
+        if (host_out) { (void)hipHostFree(host_out); host_out = nullptr; host_out_bytes = 0; }
+        tile_ids.release(); tile_w = tile_h = 0;
         for (DevBuf *b : {&accum, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear, &scene_cache}) b->release();
         for (Lane &l : lanes) {
             for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount, &l.park_a, &l.park_b, &l.park_m, &l.pcount}) b->release();
@@ -333,6 +343,8 @@ struct Flattener {
     bool any_attr = false;
     PairBvh blas;                 // all meshes' trees, as walked on the device
     uint32_t blas_depth = 0, ref_blas_nodes = 0, max_tris = 0;
+    std::vector<ShapeParams> mesh_cache;  // per shape index: a TriangleMesh shape referenced by several objects (or by a medium
+    std::vector<uint8_t> mesh_cached;     // and an object) is flattened and built once, every user shares its triangles and BLAS
 
     int check_material(int32_t m) const { return (m < 0 || (uint32_t)m >= d->n_materials) ? FW_ERR_BAD_ARG : FW_OK; }
 
@@ -379,7 +391,12 @@ struct Flattener {
             sp.flags |= fw::OF_GATE;
             sp.true_box = {{-s.radius, -0.001f, -s.radius}, {s.radius, 0.001f, s.radius}};
             return FW_OK;
-        case FW_SHAPE_TRIANGLE_MESH: return mesh_params(s, sp);
+        case FW_SHAPE_TRIANGLE_MESH: {
+            if (mesh_cached.empty()) { mesh_cached.assign(d->n_shapes, 0); mesh_cache.resize(d->n_shapes); }
+            if (mesh_cached[si]) { sp = mesh_cache[si]; return FW_OK; }
+            int rc = mesh_params(s, sp);
+            if (rc == FW_OK) { mesh_cache[si] = sp; mesh_cached[si] = 1; }
+            return rc; }
         case FW_SHAPE_CONSTANT_MEDIUM: {                             // volume.rs:84-86: bbox of the inner shape
             if (nest > 0) return fail(FW_ERR_UNSUPPORTED, "ConstantMedium nested in a ConstantMedium");
             ShapeParams in;
@@ -462,6 +479,11 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         cu_cache[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int n_cus_dev = device < MAX_DEVICES ? cu_cache[device] : 256;
+    // FIREWORK_TRACE=1: where a scene creation spends its time (host flatten + BVH builds | staging blob | alloc | copy)
+    const bool trace = getenv("FIREWORK_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    const auto tr0 = now();
 
     Flattener fl{desc};
     std::vector<float> objs((size_t)desc->n_objects * fw::OBJ_Q * 4, 0.f);
@@ -627,14 +649,44 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         {cull.data(), cull.size() * 4, 0}};
     size_t total = 0;
     for (Sec &x : secs) { x.off = total; total += (x.bytes + 255) & ~(size_t)255; }
-    total = std::max<size_t>(total, 256);
-    std::vector<uint8_t> blob(total, 0);
-    for (const Sec &x : secs) if (x.bytes) std::memcpy(blob.data() + x.off, x.src, x.bytes);
-    if (Workspace *ws = workspace_for(device)) {     // reuse the previous scene's allocation when it is big enough
-        std::lock_guard<std::mutex> g(ws->mu);
-        if (ws->scene_cache.p && ws->scene_cache.bytes >= blob.size()) { sc->data = ws->scene_cache; ws->scene_cache = DevBuf{}; }
+    total = std::max<size_t>(total, 256);                  // a multiple of 256: k_upload copies 16-byte words
+    const double tr_build = ms_since(tr0);
+    const auto tr1 = now();
+    Workspace *ws = workspace_for(device);
+    if (!ws) { delete sc; return fail(FW_ERR_OOM, "no workspace for this device"); }
+    std::lock_guard<std::mutex> ws_guard(ws->mu);
+    // the blob is assembled in pinned host memory (grown on demand, kept per device) and copied by a kernel on the null
+    // stream; renders of this scene wait for ws->ev_upload in stream order, the host never blocks here
+    if (ws->ev_upload) (void)hipEventSynchronize(ws->ev_upload);          // the previous upload has read the staging buffer (long done)
+    else if (hipEventCreateWithFlags(&ws->ev_upload, hipEventDisableTiming) != hipSuccess) { delete sc; return fail(FW_ERR_HIP, "hipEventCreate failed"); }
+    if (ws->staging_bytes < total) {
+        if (ws->staging) (void)hipHostFree(ws->staging);
+        ws->staging = nullptr; ws->staging_bytes = 0;
+        const size_t want = std::max<size_t>(total + total / 4, 1 << 20);
+        if (hipHostMalloc(&ws->staging, want, hipHostMallocDefault) != hipSuccess) { delete sc; return fail(FW_ERR_OOM, "pinned staging allocation failed"); }
+        ws->staging_bytes = want;
     }
-    rc = sc->data.upload(blob.data(), blob.size());
+    uint8_t *blob = (uint8_t *)ws->staging;
+    size_t prev_end = 0;
+    for (const Sec &x : secs) {       // sections + zeroed padding between them
+        if (x.off > prev_end) std::memset(blob + prev_end, 0, x.off - prev_end);
+        if (x.bytes) std::memcpy(blob + x.off, x.src, x.bytes);
+        prev_end = x.off + x.bytes;
+    }
+    if (total > prev_end) std::memset(blob + prev_end, 0, total - prev_end);
+    const double tr_blob = ms_since(tr1);
+    if (ws->scene_cache.p && ws->scene_cache.bytes >= total) { sc->data = ws->scene_cache; ws->scene_cache = DevBuf{}; }   // reuse the previous scene's allocation
+    const auto tr2 = now();
+    const bool reused = sc->data.p != nullptr;
+    rc = sc->data.alloc(total);
+    const double tr_alloc = ms_since(tr2);
+    const auto tr3 = now();
+    if (!rc) {
+        fw::launch_upload(nullptr, blob, sc->data.p, total);
+        if (hipEventRecord(ws->ev_upload, nullptr) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(FW_ERR_HIP, "scene upload failed");
+    }
+    if (trace) fprintf(stderr, "[firework] scene_create: build %.2f ms, blob %.2f ms (%zu B), alloc %.2f ms (%s), upload launch %.2f ms\n",
+                       tr_build, tr_blob, total, tr_alloc, reused ? "cached" : "hipMalloc", ms_since(tr3));
     if (rc) { delete sc; return rc; }
     const uint8_t *base = (const uint8_t *)sc->data.p;
     fw::DScene &d = sc->d;
@@ -704,6 +756,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     if (n_pix == 0) return fail(FW_ERR_BAD_ARG, "no pixels to render");
     if ((uint64_t)first_sample + p->samples > 0xffffffffull) return fail(FW_ERR_BAD_ARG, "first_sample + samples overflows");
     if (p->pixel_ids) for (uint32_t i = 0; i < n_pix; i++) if (p->pixel_ids[i] >= full) return fail(FW_ERR_BAD_ARG, "pixel id out of range");
+    const auto wall0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(sc->device));
     hipStream_t stream = (hipStream_t)p->stream;
     Workspace *ws = workspace_for(sc->device);
@@ -754,13 +807,17 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         need(L.sample_rad, (size_t)cap * 16);                 // indexed by home slot
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
         if (park_meshes) {     // rays handed from k_extend_tlas_park to k_blas: 40 B per slot
-            need(L.park_a, (size_t)cap * 16); need(L.park_b, (size_t)cap * 8); need(L.park_m, (size_t)cap * 16); need(L.pcount, (size_t)q.n_waves * 4);
+            need(L.park_a, (size_t)cap * 16); need(L.park_b, (size_t)cap * 8); need(L.park_m, (size_t)cap * 16); need(L.pcount, (size_t)q.n_waves * 8);   // pcount[n_waves] + ptotal[n_waves]
         }
         if (!rc && !L.stream && n_lanes > 1) HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     }
     need(ws->accum, (size_t)n_pix * 16);
     need(ws->totals, (size_t)n_batches * fw::COUNT_STRIDE * 4);
     if (p->pixel_ids) need(ws->pixel_ids, (size_t)n_pix * 4);
+    // a whole frame is traced in the library's own 16x16-tile order (k_tile_order); k_resolve undoes it.  Not for progressive
+    // renders: their accumulation buffer belongs to the caller and stays in pixel order.
+    const bool own_order = !p->pixel_ids && !user_accum && n_pix >= 1024 && getenv("FIREWORK_NO_TILE_ORDER") == nullptr;
+    if (own_order) { const void *before = ws->tile_ids.p; need(ws->tile_ids, (size_t)n_pix * 4); if (ws->tile_ids.p != before) ws->tile_w = ws->tile_h = 0; }
     uint8_t *d_rgb8 = rgb8; float *d_gamma = gamma_rgb, *d_linear = linear_rgb;
     if (!p->outputs_on_device) {
         if (rgb8) { need(ws->out_rgb8, (size_t)n_pix * 3); d_rgb8 = (uint8_t *)ws->out_rgb8.p; }
@@ -770,7 +827,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     if (rc) return rc;
     while (ws->events.size() < 3 + (size_t)n_batches) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, ws->events.size() < 2 ? hipEventDefault : hipEventDisableTiming)); ws->events.push_back(e); }
 
+    if (ws->ev_upload) HIPCHK(hipStreamWaitEvent(stream, ws->ev_upload, 0));     // the scene's upload kernel (null stream)
     if (p->pixel_ids) HIPCHK(hipMemcpyAsync(ws->pixel_ids.p, p->pixel_ids, (size_t)n_pix * 4, hipMemcpyHostToDevice, stream));
+    if (own_order && (ws->tile_w != p->width || ws->tile_h != p->height)) {
+        ws->tile_w = ws->tile_h = 0;                                               // invalid until the launch below has been queued
+        fw::launch_tile_order(stream, p->width, p->height, (uint32_t *)ws->tile_ids.p);
+        ws->tile_w = p->width; ws->tile_h = p->height;
+    }
     if (user_accum)     // resume: the sums of the samples rendered so far (host or device memory, like the outputs)
         HIPCHK(hipMemcpyAsync(ws->accum.p, user_accum, (size_t)n_pix * 16, p->outputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
     else HIPCHK(hipMemsetAsync(ws->accum.p, 0, (size_t)n_pix * 16, stream));
@@ -789,7 +852,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
     fr.width = p->width; fr.height = p->height; fr.n_pixels = n_pix; fr.inv_n_pixels = 1.0f / (float)n_pix; fr.inv_width = 1.0f / (float)p->width;
-    fr.pixel_ids = p->pixel_ids ? (const uint32_t *)ws->pixel_ids.p : nullptr;
+    fr.pixel_ids = p->pixel_ids ? (const uint32_t *)ws->pixel_ids.p : (own_order ? (const uint32_t *)ws->tile_ids.p : nullptr);
+    fr.scatter_out = own_order ? 1u : 0u;
     fr.seed32 = (uint32_t)p->seed ^ ((uint32_t)(p->seed >> 32) * 0x9E3779B9u);
     fr.q_n_waves = q.n_waves; fr.q_shift = q.cpw_shift;
     fr.cam_pos[0] = cam.position[0]; fr.cam_pos[1] = cam.position[1]; fr.cam_pos[2] = cam.position[2];
@@ -801,6 +865,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // per-launch timing (FW_FLAG_TIME_KERNELS): one event after every launch on the launch's own stream; the end of
     // launch k is the start of launch k+1 of that lane.  With several lanes the intervals overlap in wall time.
     const bool timing = (p->flags & FW_FLAG_TIME_KERNELS) != 0;
+    const bool count_deposits = (p->flags & FW_FLAG_COUNT_DEPOSITS) != 0 && fr.skip_zero_deposits != 0;   // otherwise every terminated path writes one
     const size_t per_batch_launches = 1 + 2 * fw::MAX_SEGMENTS + 2;
     std::vector<std::vector<int>> ev_class(n_lanes);   // per lane: class of the launch that ENDS at events[1 + k]
     std::vector<size_t> ev_next(n_lanes, 0);
@@ -840,7 +905,9 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         for (int k = 0; k < 2; k++) buf[k] = {(float4 *)L.ray_a[k].p, (float2 *)L.ray_b[k].p, (float4 *)L.state[k].p};
         float2 *hits = (float2 *)L.hits.p;
         float4 *srad = (float4 *)L.sample_rad.p, *accum = (float4 *)ws->accum.p;
-        const fw::DPark park{(float4 *)L.park_a.p, (float2 *)L.park_b.p, (float4 *)L.park_m.p, (uint32_t *)L.pcount.p};
+        const fw::DPark park{(float4 *)L.park_a.p, (float2 *)L.park_b.p, (float4 *)L.park_m.p, (uint32_t *)L.pcount.p,
+                             park_meshes ? (uint32_t *)L.pcount.p + q.n_waves : nullptr};
+        if (park_meshes) HIPCHK(hipMemsetAsync(park.ptotal, 0, (size_t)q.n_waves * 4, ls));
         int cur = 0;
         timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], srad, n_paths); });
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
@@ -851,7 +918,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             }
             cur ^= 1;
         }
-        timed(3, [&] { fw::launch_queue_totals(cfg, totals); });
+        timed(3, [&] { fw::launch_queue_totals(cfg, totals, park.ptotal); });
+        if (count_deposits) fw::launch_count_deposits(cfg, srad, cap, totals + 12);   // not a kernel class: after the last timed event of its neighbours
         // `total_color += color(..)` in sample order (render.rs:181): batch b is accumulated after batch b-1, whichever
         // lanes they ran on, so the image does not depend on the number of lanes or batches
         if (n_lanes > 1 && b > 0) HIPCHK(hipStreamWaitEvent(ls, ws->events[3 + b - 1], 0));
@@ -865,20 +933,75 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     HIPCHK(hipEventRecord(ws->events[1], stream));
     HIPCHK(hipGetLastError());
 
-    std::vector<uint32_t> h_counts((size_t)n_batches * fw::COUNT_STRIDE);
-    HIPCHK(hipMemcpyAsync(h_counts.data(), ws->totals.p, h_counts.size() * 4, hipMemcpyDeviceToHost, stream));
-    if (!p->outputs_on_device) {
-        if (rgb8) HIPCHK(hipMemcpyAsync(rgb8, d_rgb8, (size_t)n_pix * 3, hipMemcpyDeviceToHost, stream));
-        if (gamma_rgb) HIPCHK(hipMemcpyAsync(gamma_rgb, d_gamma, (size_t)n_pix * 12, hipMemcpyDeviceToHost, stream));
-        if (linear_rgb) HIPCHK(hipMemcpyAsync(linear_rgb, d_linear, (size_t)n_pix * 12, hipMemcpyDeviceToHost, stream));
+    const bool trace = getenv("FIREWORK_TRACE") != nullptr;
+    const auto tq0 = std::chrono::steady_clock::now();
+    auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    // Device -> host through PINNED memory, then a host memcpy into the caller's buffers.  A hipMemcpyAsync into pageable
+    // memory blocks inside the runtime until the stream has drained, and that wait returned 15-30 ms late every few calls
+    // (FIREWORK_TRACE=1, tools/oneshot.py: "counters copy returned +69 ms" for 43 ms of device work); with pinned
+    // destinations the copies are queued and the only host wait is the hipStreamSynchronize below.
+    const size_t n_counts = (size_t)n_batches * fw::COUNT_STRIDE;
+    const size_t off_c = 0, off_8 = (n_counts * 4 + 255) & ~(size_t)255;
+    const size_t off_g = off_8 + ((!p->outputs_on_device && rgb8 ? (size_t)n_pix * 3 : 0) + 255 & ~(size_t)255);
+    const size_t off_l = off_g + ((!p->outputs_on_device && gamma_rgb ? (size_t)n_pix * 12 : 0) + 255 & ~(size_t)255);
+    const size_t host_need = off_l + (!p->outputs_on_device && linear_rgb ? (size_t)n_pix * 12 : 0) + 256;
+    if (ws->host_out_bytes < host_need) {
+        if (ws->host_out) (void)hipHostFree(ws->host_out);
+        ws->host_out = nullptr; ws->host_out_bytes = 0;
+        if (hipHostMalloc(&ws->host_out, host_need + host_need / 4, hipHostMallocDefault) != hipSuccess) return fail(FW_ERR_OOM, "pinned output staging allocation failed");
+        ws->host_out_bytes = host_need + host_need / 4;
     }
+    uint8_t *ho = (uint8_t *)ws->host_out;
+    const uint32_t *h_counts = (const uint32_t *)(ho + off_c);
+    HIPCHK(hipMemcpyAsync(ho + off_c, ws->totals.p, n_counts * 4, hipMemcpyDeviceToHost, stream));
+    const double t_counts = since(tq0);
+    if (!p->outputs_on_device) {
+        if (rgb8) HIPCHK(hipMemcpyAsync(ho + off_8, d_rgb8, (size_t)n_pix * 3, hipMemcpyDeviceToHost, stream));
+        if (gamma_rgb) HIPCHK(hipMemcpyAsync(ho + off_g, d_gamma, (size_t)n_pix * 12, hipMemcpyDeviceToHost, stream));
+        if (linear_rgb) HIPCHK(hipMemcpyAsync(ho + off_l, d_linear, (size_t)n_pix * 12, hipMemcpyDeviceToHost, stream));
+    }
+    const double t_outs = since(tq0);
+    if (!ws->ev_d2h) HIPCHK(hipEventCreate(&ws->ev_d2h));
+    HIPCHK(hipEventRecord(ws->ev_d2h, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    if (!p->outputs_on_device) {
+        if (rgb8) std::memcpy(rgb8, ho + off_8, (size_t)n_pix * 3);
+        if (gamma_rgb) std::memcpy(gamma_rgb, ho + off_g, (size_t)n_pix * 12);
+        if (linear_rgb) std::memcpy(linear_rgb, ho + off_l, (size_t)n_pix * 12);
+    }
+    if (trace) fprintf(stderr, "[firework] render: enqueue %.2f ms | counters copy queued +%.2f | output copies queued +%.2f | sync + host memcpy returned +%.2f\n",
+                       std::chrono::duration<double, std::milli>(tq0 - wall0).count(), t_counts, t_outs, since(tq0));
+    const auto wall1 = std::chrono::steady_clock::now();
 
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->samples = (uint64_t)n_pix * p->samples;
-        for (uint32_t b = 0; b < n_batches; b++)
+        uint64_t deposits = 0;
+        for (uint32_t b = 0; b < n_batches; b++) {
             for (int s = 0; s < fw::MAX_SEGMENTS; s++) { uint64_t c = h_counts[(size_t)b * fw::COUNT_STRIDE + s]; stats->rays_per_depth[s] += c; stats->rays += c; }
+            stats->parked_rays += h_counts[(size_t)b * fw::COUNT_STRIDE + fw::MAX_SEGMENTS];
+            deposits += h_counts[(size_t)b * fw::COUNT_STRIDE + 12];
+        }
+        stats->deposits = count_deposits ? deposits : stats->samples;      // every path ends exactly once (render.rs:19-31)
+        {   // HBM bytes this layout moves (fw_device.h B_*): queue streams only, scene tables are cache-resident
+            const uint64_t *R = stats->rays_per_depth;
+            const uint64_t S = stats->samples, ray0 = fr.pinhole0 ? fw::B_RAY_PINHOLE0 : fw::B_RAY;
+            uint64_t rd_ray = R[0] * ray0, later = 0, survivors = 0;
+            for (int s = 1; s < fw::MAX_SEGMENTS; s++) { rd_ray += R[s] * fw::B_RAY; later += R[s]; survivors += R[s]; }
+            stats->bytes_raygen = S * ray0 + (fr.skip_zero_deposits ? S * fw::B_DEPOSIT : 0) + (fr.pixel_ids ? S * 4 : 0);
+            const uint64_t medium = sc->d.has_medium ? later * 4 : 0;       // the path's home slot (RNG key of the medium's draw)
+            const uint64_t shade_in = rd_ray + later * fw::B_STATE, shade_out = survivors * (fw::B_RAY + fw::B_STATE) + stats->deposits * fw::B_DEPOSIT;
+            if (fused) { stats->bytes_extend = 0; stats->bytes_shade = shade_in + shade_out; }
+            else {
+                stats->bytes_extend = rd_ray + medium + stats->rays * fw::B_HIT + stats->parked_rays * 2 * fw::B_PARK;
+                stats->bytes_shade = shade_in + stats->rays * fw::B_HIT + shade_out;
+            }
+            stats->bytes_accumulate = S * fw::B_DEPOSIT + (uint64_t)n_batches * n_pix * 2 * fw::B_ACCUM;
+        }
+        stats->ms_wall = std::chrono::duration<double, std::milli>(wall1 - wall0).count();
+        float ms_copy = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms_copy, ws->events[1], ws->ev_d2h));   // counters (a few hundred bytes) + the outputs
+        stats->ms_d2h = ms_copy;
         stats->algorithmic_bytes = 160 * stats->rays + 24 * stats->samples;   // SURVEY §8(d); HDR env misses are added by the caller that knows them
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ws->events[0], ws->events[1]));
@@ -984,6 +1107,7 @@ int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *par
     if (!desc || !params || !devices || n_devices <= 0) return fail(FW_ERR_BAD_ARG, "null argument");
     if (params->pixel_ids || params->outputs_on_device) return fail(FW_ERR_BAD_ARG, "fw_render_scene_tiled renders whole frames into host buffers");
     if (params->width == 0 || params->height == 0) return fail(FW_ERR_BAD_ARG, "width, height and samples must be > 0");
+    const auto call0 = std::chrono::steady_clock::now();
     try {
         const uint32_t W = params->width, H = params->height, TILE = 16, tx = (W + TILE - 1) / TILE, ty = (H + TILE - 1) / TILE;
         const int N = n_devices;
@@ -1028,12 +1152,16 @@ int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *par
             }
             if (stats && !ids[r].empty()) {
                 stats->samples += pt.st.samples; stats->rays += pt.st.rays; stats->algorithmic_bytes += pt.st.algorithmic_bytes;
+                stats->bytes_raygen += pt.st.bytes_raygen; stats->bytes_extend += pt.st.bytes_extend; stats->bytes_shade += pt.st.bytes_shade;
+                stats->bytes_accumulate += pt.st.bytes_accumulate; stats->deposits += pt.st.deposits; stats->parked_rays += pt.st.parked_rays;
+                stats->ms_d2h = std::max(stats->ms_d2h, pt.st.ms_d2h);
                 for (int k = 0; k < FW_MAX_SEGMENTS; k++) stats->rays_per_depth[k] += pt.st.rays_per_depth[k];
                 stats->ms_render = std::max(stats->ms_render, pt.st.ms_render); stats->ms_scene = std::max(stats->ms_scene, pt.ms_scene);
                 stats->n_batches = std::max(stats->n_batches, pt.st.n_batches);
                 stats->tlas_nodes = pt.st.tlas_nodes; stats->blas_nodes = pt.st.blas_nodes; stats->reserved = pt.st.reserved;
             }
         }
+        if (stats) stats->ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - call0).count();
         return FW_OK;
     }
     catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
@@ -1056,8 +1184,11 @@ int fw_render_scene(const fw_scene_desc *desc, const fw_render_params *params, i
     if (rc) return rc;
     double ms_scene = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     rc = fw_render(sc, params, rgb8, gamma_rgb, linear_rgb, stats);
-    if (!rc && stats) stats->ms_scene = ms_scene;
     fw_scene_destroy(sc);
+    if (!rc && stats) {
+        stats->ms_scene = ms_scene;
+        stats->ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();   // main.rs:40-44's region
+    }
     return rc;
 }
 

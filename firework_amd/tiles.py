@@ -45,10 +45,12 @@ def tile_pixel_ids(width, height, rank, world, tile=TILE, scheme="diagonal"):
 class TileGather:
     """Rank bookkeeping + the one collective.  Device-agnostic (cuda tensors with nccl, cpu tensors with gloo)."""
 
-    def __init__(self, width, height, rank, world, device, dist=None, tile=TILE, host_staged=False):
+    def __init__(self, width, height, rank, world, device, dist=None, tile=TILE, host_staged=False, force_collective=False):
         import torch
         self.torch, self.dist = torch, dist
-        self.host_staged = host_staged and world > 1
+        # force_collective: a 1-rank group still sends its tiles through dist.gather (the RCCL call on one GPU)
+        self.collective = world > 1 or (force_collective and dist is not None)
+        self.host_staged = host_staged and self.collective
         self.width, self.height, self.rank, self.world, self.device = width, height, rank, world, device
         all_ids = [tile_pixel_ids(width, height, r, world, tile) for r in range(world)]
         self.ids = np.ascontiguousarray(all_ids[rank])
@@ -59,12 +61,12 @@ class TileGather:
         if rank == 0:
             self.frame = torch.zeros((width * height, 3), dtype=torch.uint8, device=device)
             self.all_ids_dev = [torch.from_numpy(a.astype(np.int64)).to(device) for a in all_ids]
-            if world > 1:
+            if self.collective:
                 self.gather_list = [torch.zeros((self.n_max, 3), dtype=torch.uint8, device=device) for _ in range(world)]
 
     def assemble(self):
         """`self.local[:n_local]` holds this rank's finished pixels -> full frame on rank 0 (None elsewhere)."""
-        if self.world == 1:
+        if not self.collective:
             self.frame.index_copy_(0, self.all_ids_dev[0], self.local[: self.n_local])
             return self.frame
         # the only collective of the whole path: <= W*H*3 bytes in total
@@ -87,14 +89,18 @@ class TiledRenderer:
     """One process per GPU: uploaded scene + this rank's tiles; `render_frame()` = local fw_render into HBM
     + TileGather.assemble()."""
 
-    def __init__(self, scene, renderer, rank=0, world=1, device=0, tile=TILE, dist=None, host_staged_gather=False):
+    def __init__(self, scene, renderer, rank=0, world=1, device=0, tile=TILE, dist=None, host_staged_gather=False,
+                 force_collective=False):
         import torch
         from . import _lib
         self.torch, self.renderer = torch, renderer
         s = renderer.settings
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
-        self.tg = TileGather(s["width"], s["height"], rank, world, self.dev, dist, tile, host_staged=host_staged_gather)
+        self.tg = TileGather(s["width"], s["height"], rank, world, self.dev, dist, tile, host_staged=host_staged_gather,
+                             force_collective=force_collective)
+        self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.last_ms_gather = 0.0
         self.scene = _lib.DeviceScene(scene if hasattr(scene, "ptr") else scene.to_desc(), device)
         self.world = world
         self.last_stats = None
@@ -105,7 +111,12 @@ class TiledRenderer:
         stream = self.torch.cuda.current_stream(self.dev).cuda_stream
         self.last_stats = self.scene.render(self.renderer, pixel_ids=self.tg.ids,
                                             out_device_ptrs=(self.tg.local.data_ptr(), None, None), stream=stream)
+        # the gather (and the scatter of the tiles into the frame) on torch's current stream = the stream fw_render ran on
+        self.ev[0].record()
         self.frame = self.tg.assemble()
+        self.ev[1].record()
+        self.ev[1].synchronize()
+        self.last_ms_gather = self.ev[0].elapsed_time(self.ev[1])
         return self.frame
 
     def close(self):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 3   /* 3: + fw_render_progressive */
+#define FW_ABI_VERSION 4   /* 3: + fw_render_progressive; 4: fw_stats carries this layout's own HBM bytes per kernel class and the one-shot timings */
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum fw_status {
@@ -202,6 +202,9 @@ typedef struct fw_render_params {
 } fw_render_params;
 
 #define FW_FLAG_TIME_KERNELS 1u  /* bracket every launch with HIP events and fill fw_stats.ms_<class> */
+#define FW_FLAG_COUNT_DEPOSITS 2u /* count the radiance records k_shade really wrote (one extra pass over the sample buffer per
+                                     batch, outside the kernel classes' times): makes fw_stats.bytes_shade exact when zero
+                                     deposits are elided over a black environment; without it they are counted as written */
 
 #define FW_MAX_SEGMENTS 11  /* depths 0..10: render.rs:21 */
 
@@ -217,6 +220,13 @@ typedef struct fw_stats {
                                                                  intersect+shade launches are counted and timed as shade */
     uint32_t tlas_nodes, blas_nodes;
     uint32_t reserved;
+    /* HBM bytes THIS layout has to move, per kernel class, exact from the queue counters (DESIGN.md §5 gives the per-ray
+       figures; SURVEY's generic 160 B/ray formula stays in algorithmic_bytes): what roofline fractions are computed from. */
+    uint64_t bytes_raygen, bytes_extend, bytes_shade, bytes_accumulate;
+    uint64_t deposits;                       /* radiance records written by k_shade (FW_FLAG_COUNT_DEPOSITS), else the terminated paths */
+    uint64_t parked_rays;                    /* rays handed from the TLAS walk to k_blas (use_bvh with meshes) */
+    double ms_wall;                          /* host wall time of the whole call (fw_render_scene: conversion + BVH + upload + render + D2H) */
+    double ms_d2h;                           /* device -> host copies of the outputs (0 when outputs_on_device) */
 } fw_stats;
 
 typedef struct fw_scene fw_scene;  /* opaque: flattened SoA scene + BVHs resident in HBM */

@@ -237,6 +237,27 @@ def test_progressive_passes_and_a_resumed_checkpoint_equal_one_render(tmp_path):
         next(gen); gen.close()                                                 # "killed" after the first pass
         resumed = list(r.render_progressive(s, 3, checkpoint=ck))
         assert len(resumed) == 2 and np.array_equal(resumed[-1].linear, full.linear)
+    # a checkpoint of ANOTHER scene / camera / use_bvh is not blended in; a name without .npz is the file np.savez writes;
+    # a truncated file restarts from zero instead of crashing
+    s, r = scenes.config("C2_cornell_box", 48, 36, 12)
+    full = r.render_full(s)
+    ck = str(tmp_path / "ck")                                                  # no extension
+    gen = r.render_progressive(s, 3, checkpoint=ck)
+    next(gen); gen.close()
+    import os
+    assert os.path.exists(ck + ".npz") and not os.path.exists(ck)
+    assert len(list(r.render_progressive(s, 3, checkpoint=ck))) == 2           # found and resumed
+    s2, r2 = scenes.config("C3_suzanne", 48, 36, 12)
+    other = list(r2.render_progressive(s2, 3, checkpoint=ck))                  # same size and seed, other scene
+    assert len(other) == 3 and np.array_equal(other[-1].linear, r2.render_full(s2).linear)
+    cam2 = CameraSettings.default().cam_pos((278.0, 278.0, -700.0)).look_at((278.0, 278.0, 0.0)).field_of_view(40.0)
+    gen = r.render_progressive(s, 3, checkpoint=ck); next(gen); gen.close()
+    moved = list(r.camera(cam2).render_progressive(s, 3, checkpoint=ck))       # same scene, other camera
+    assert len(moved) == 3 and np.array_equal(moved[-1].linear, r.render_full(s).linear)
+    with open(ck + ".npz", "r+b") as f:
+        f.truncate(100)
+    again = list(r.render_progressive(s, 2, checkpoint=ck))
+    assert len(again) == 2 and np.array_equal(again[-1].linear, r.render_full(s).linear)
 
 
 def test_single_process_tiled_render_is_bit_identical():

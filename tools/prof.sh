@@ -1,7 +1,18 @@
-# rocprofv3 evidence for profiles/: kernel trace + separate PMC passes (FETCH_SIZE, WRITE_SIZE)
-export TMPDIR=/tmp; R=$PWD; rm -rf $R/gpurun_out/prof; mkdir -p $R/gpurun_out/prof && cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof/trace.log 2>&1 &&
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof/fetch -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/prof/fetch.log 2>&1 &&
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof/write -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $R/gpurun_out/prof/write.log 2>&1
-echo prof exit $?
-tail -1 $R/gpurun_out/prof/trace.log | cut -c1-300
+# rocprofv3 evidence for profiles/: kernel trace + separate PMC passes.  usage: bash tools/prof.sh <dir tag> [bench args...]
+#   e.g.  bash tools/prof.sh prof_c2                      (the bench config)
+#         bash tools/prof.sh prof_c3 --config C3_suzanne --spp 64
+# then:   python3 scripts/summarize_prof.py gpurun_out/<dir tag> <profiles tag> "<workload>"
+TAG=$1; shift
+export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O && cd /tmp
+B="--no-cpu-baseline --no-one-shot"
+pass() { local name=$1; shift; local ctr="$1"; shift
+  if [ -n "$ctr" ]; then timeout -k 10 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$name -- python3 $R/bench.py "$@" --steps 1 --warmup 0 $B > $O/$name.log 2>&1
+  else timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -- python3 $R/bench.py "$@" --steps 3 --warmup 1 $B > $O/$name.log 2>&1; fi
+  echo "prof $TAG $name rc=$?"; }
+pass trace "" "$@" &&
+pass fetch "FETCH_SIZE" "$@" &&
+pass write "WRITE_SIZE" "$@" &&
+pass sqa "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD" "$@" &&
+pass sqb "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAVES SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES" "$@" &&
+pass tcc "TCC_HIT_sum TCC_MISS_sum" "$@"
+tail -1 $O/trace.log | cut -c1-400
