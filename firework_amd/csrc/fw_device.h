@@ -132,6 +132,8 @@ struct DQueue {
 // best t so far, best hit code so far).
 struct DPark {
     float4 *ray_a; float2 *ray_b; float4 *meta;
+    uint32_t stride;    // slots per wave region: q.cap + 64 (a wave that streams several queues parks the rays still in flight
+                        // from the previous queue into the region of the one it has open)
     uint32_t *pcount;
     uint32_t *ptotal;   // per wave: parked rays over all segments of the batch (statistics; zeroed per batch)
 };
@@ -153,8 +155,15 @@ struct LaunchCfg {
     uint32_t n_mat, n_tex;        // table sizes (for the LDS-resident copy in k_shade)
     bool lds_tables;              // stage small scene tables in LDS (debug switch: FIREWORK_NO_LDS_TABLES)
     bool has_mesh;
+    int stream_waves;     // physical waves of the refilling walks (k_extend_tlas*, k_blas): each streams n_waves / stream_waves
+                          // consecutive wave queues back to back, so that only its LAST rays run in a thinning wave
+    int n_cus;
+    uint32_t blas_pair_nodes, tlas_pair_nodes, max_tris, n_tris;   // n_tris: all meshes together
+    bool no_lds_tris;     // A/B switch FIREWORK_NO_LDS_TRIS   // sizes of the walked trees (pair nodes) and of the biggest mesh
+    bool lds_trees;       // walk trees that fit out of LDS (k_blas_lds); FIREWORK_NO_LDS_TREES=1 switches it off
     bool tlas_refill;     // refilling walks: k_extend_tlas (no meshes) / k_extend_tlas_park + k_blas (meshes); FIREWORK_TLAS_REFILL=0: the chunked k_extend_bvh
 };
+constexpr size_t LDS_TREE_LIMIT = 160 * 1024;   // the whole LDS of a CU: one workgroup of the LDS-resident walks per CU
 constexpr size_t LDS_TABLE_LIMIT = 16 * 1024;   // object+material+texture tables up to this size are staged in LDS
 
 void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, float4 *sample_rad, uint32_t n_paths);

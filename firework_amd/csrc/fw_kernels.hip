@@ -213,11 +213,13 @@ constexpr int WB = FW_WB;
 __device__ unsigned long long g_trav[8];
 __shared__ float g_ts[8 * 64];
 #define TS_TICK(k) do { float pc_ = (float)__popcll(__ballot(1)); g_ts[(k) * 64 + (threadIdx.x & 63u)] += 1.f; g_ts[((k) + 1) * 64 + (threadIdx.x & 63u)] += 64.f / pc_; } while (0)
+#define TS_COUNT(k, pred) do { g_ts[(k) * 64 + (threadIdx.x & 63u)] += (pred) ? 1.f : 0.f; g_ts[((k) + 1) * 64 + (threadIdx.x & 63u)] += 1.f; } while (0)
 #define TS_BEGIN() do { for (int k_ = 0; k_ < 8; k_++) g_ts[k_ * 64 + (threadIdx.x & 63u)] = 0.f; } while (0)
 #define TS_END() do { for (int k_ = 0; k_ < 8; k_++) { float v_ = g_ts[k_ * 64 + (threadIdx.x & 63u)]; for (int o_ = 32; o_ > 0; o_ >>= 1) v_ += __shfl_xor(v_, o_); \
                       if ((threadIdx.x & 63u) == 0) atomicAdd(&g_trav[k_], (unsigned long long)(v_ + 0.5f)); } } while (0)
 #else
 #define TS_TICK(k) do { } while (0)
+#define TS_COUNT(k, pred) do { } while (0)
 #define TS_BEGIN() do { } while (0)
 #define TS_END() do { } while (0)
 #endif
@@ -549,6 +551,13 @@ struct LdsStack {
     __device__ __forceinline__ void push(uint32_t v) { s[sp * FW_WB] = v; sp++; }
     __device__ __forceinline__ uint32_t pop() { sp--; return s[sp * FW_WB]; }
 };
+// The same with 16-bit entries (trees of fewer than 2^15 nodes and items: bit 15 = leaf flag), [level][lane] over the 64 lanes
+// of ONE wave: half the LDS, which is what lets a 1024-thread workgroup keep 16 stacks next to a whole tree (k_blas_lds).
+struct LdsStack16 {
+    uint16_t *s; int sp;
+    __device__ __forceinline__ void push(uint32_t v) { s[sp * 64] = (uint16_t)((v & 0x7fffu) | ((v >> 16) & 0x8000u)); sp++; }
+    __device__ __forceinline__ uint32_t pop() { sp--; const uint32_t e = s[sp * 64]; return (e & 0x7fffu) | ((e & 0x8000u) << 16); }
+};
 
 // One step of a walk over PAIR NODES (fw_device.h: a node holds the boxes of BOTH its children, so one 64-byte fetch
 // decides two boxes; with one box per node every box test waited for its own dependent fetch and the walk was
@@ -557,8 +566,9 @@ struct LdsStack {
 // is not clearly beyond the best hit so far: `cull` = cull_bound(best t) = best t + 1e-6 |best t|.  The slack covers the few ulp by which a
 // computed slab entry can exceed the t of a hit lying on the box face, and keeps exact ties (which the in-order rank
 // decides) reachable — so the result does not depend on the shape of the walked tree.
+template <class Stack>
 __device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, uint32_t node, V3 o, V3 inv, float tmin, float tmax,
-                                              float cull, LdsStack &st) {
+                                              float cull, Stack &st) {
     const float4 *nd = nodes + 4 * (size_t)node;
     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
     float tl, tr;
@@ -706,6 +716,55 @@ constexpr uint32_t WALK_NUM = FW_WALK_NUM, WALK_DEN = FW_WALK_DEN;   // same rul
 static_assert(FW_BLAS_WALK_NUM > FW_BLAS_WALK_DEN, "the walk must continue while every busy lane walks");
 constexpr uint32_t BLAS_WALK_NUM = FW_BLAS_WALK_NUM, BLAS_WALK_DEN = FW_BLAS_WALK_DEN;   // node walking stops when walkers * NUM <= busy lanes * DEN
 static_assert(FW_WB == 64, "the parked-ray list and the wave-private queues assume single-wave workgroups");
+
+// A physical wave of the refilling walks streams the entries of SEVERAL consecutive wave queues, back to back, as blocks of
+// <= 64 (one register read-ahead buffer each).  With one queue per wave the busy lanes of k_blas averaged 55 % in the node
+// loop (tools/trav_stats.py, suzanne): every queue ends with a few long walks in an emptying wave, and a queue holds only a
+// few generations of 64 rays.  Streaming G queues leaves one such tail per G queues.  Which physical wave walks a ray does
+// not matter: every result is written to the ray's own slot.
+struct BlockStream {
+    // the wave's queues are named by an index k: queue id = q_off + k * q_mul (k-ranges are dealt statically or taken from a counter)
+    uint32_t q, q_end, q0;     // next index to open; end and start of this wave's static range
+    uint32_t q_off, q_mul;
+    uint32_t stride;           // slots per queue region
+    uint32_t base, n, off;     // the open queue: first slot, entries, offset of its next block
+    uint32_t cnt;              // lane j holds the entry count of the queue with index q0 + j (read once, at the start)
+    // dynamic mode (dyn_ctr != nullptr): after its static range the wave takes further indices, one at a time, from a counter
+    // (in LDS: the waves of a workgroup share the workgroup's queues)
+    uint32_t *dyn_ctr; const uint32_t *dyn_counts; uint32_t dyn_first, dyn_end; bool dyn_done;
+    uint32_t *ptotal;          // statistics: per-queue totals of parked rays (dynamic mode of k_blas_lds), or nullptr
+    __device__ __forceinline__ void init(const uint32_t *counts, uint32_t first, uint32_t last, uint32_t stride_, uint32_t lane,
+                                         uint32_t off_ = 0u, uint32_t mul_ = 1u) {
+        q = q0 = first; q_end = last; q_off = off_; q_mul = mul_; stride = stride_; base = 0; n = 0; off = 0;
+        cnt = (first + lane < last) ? counts[off_ + (first + lane) * mul_] : 0u;
+        dyn_ctr = nullptr; dyn_counts = counts; dyn_first = dyn_end = 0; dyn_done = true; ptotal = nullptr;
+    }
+    __device__ __forceinline__ void init_dynamic(uint32_t *ctr, uint32_t first, uint32_t end) { dyn_ctr = ctr; dyn_first = first; dyn_end = end; dyn_done = first >= end; }
+    // the next block of the stream: first slot and entry count (wave-uniform); false when the wave's queues are used up
+    __device__ __forceinline__ bool next(uint32_t &b_base, uint32_t &b_n) {
+        for (;;) {
+            if (off < n) { b_base = base + off; b_n = min(64u, n - off); off += 64u; return true; }
+            if (q >= q_end) {
+                if (dyn_done) return false;
+                uint32_t v = 0;
+                if ((threadIdx.x & 63u) == 0) v = atomicAdd(dyn_ctr, 1u);
+                const uint32_t k = dyn_first + (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                if (k >= dyn_end) { dyn_done = true; return false; }
+                const uint32_t nq = q_off + k * q_mul;
+                n = dyn_counts[nq]; base = nq * stride; off = 0;
+                if (ptotal && n && (threadIdx.x & 63u) == 0) ptotal[nq] += n;
+                continue;
+            }
+            n = (uint32_t)__shfl((int)cnt, (int)(q - q0));
+            base = (q_off + q * q_mul) * stride; off = 0; q++;
+        }
+    }
+};
+// queues [first, last) of physical wave p when n_queues are dealt to n_phys waves in runs of G = ceil(n_queues / n_phys) <= 64
+__device__ __forceinline__ void stream_range(uint32_t p, uint32_t n_queues, uint32_t n_phys, uint32_t &first, uint32_t &last) {
+    const uint32_t G = (n_queues + n_phys - 1u) / n_phys;
+    first = min(p * G, n_queues); last = min(first + G, n_queues);
+}
 
 // Closest hit of one ray: the linear scan of scene.rs:137-149 or the TLAS walk of bvh.rs:115-151.  With DEFER a
 // ray that reaches a mesh leaf of the TLAS reports (deferred, deferred_obj) instead of entering the BLAS.
@@ -919,7 +978,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                 if (pmask) {
                     const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
                     if (deferred) {
-                        const uint32_t e = base + park_n + prank;
+                        const uint32_t e = w * park.stride + park_n + prank;
                         qst(&park.ray_a[e], make_float4(r.o.x, r.o.y, r.o.z, r.d.x));
                         qst(&park.ray_b[e], make_float2(r.d.y, r.d.z));
                         qst(&park.meta[e], make_float4(__uint_as_float(i), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
@@ -936,29 +995,40 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
         // ---- TLAS walk with in-wave refill.  The chunked loop below gives every lane one ray of a 64-ray chunk and waits
         // for the slowest: on part2 only 40 % of the lanes are still busy in an average round (tools/trav_stats.py).  Here a
         // lane that has finished its ray writes the hit record (or parks the ray for its mesh) and, once TLAS_REFILL_MIN
-        // lanes are idle, the idle lanes take the next rays of the wave's queue.  The queue is read 64 rays ahead into
-        // registers (one buffer being handed out through ds_bpermute, one in flight), so a refill never waits for HBM.
-        // Same tests, same tie rules, same culling as closest_hit<true>: the bits do not change.
+        // lanes are idle, the idle lanes take the next rays of the stream.  The stream is read one block of 64 rays ahead into
+        // registers (one block being handed out through ds_bpermute, one in flight), so a refill never waits for HBM, and it
+        // runs over all the queues this physical wave was given (BlockStream), so only the wave's very last rays walk in a
+        // thinning wave.  Same tests, same tie rules, same culling as closest_hit<true>: the bits do not change.
+        // (This launch has gridDim.x PHYSICAL waves; `w` above is not a queue id here.)
+        uint32_t q_first, q_last;
+        stream_range(wave_index(), q.n_waves, gridDim.x * (WB / 64), q_first, q_last);
+        if (q_first >= q_last) { TS_END(); return; }
+        BlockStream bs;
+        bs.init(q.wcount + (size_t)segment * q.n_waves, q_first, q_last, q.cap, lane);
         float4 ca = make_float4(0, 0, 0, 0), na = ca; float2 cb = make_float2(0, 0), nb = cb; float cs = 0.f, ns = 0.f;
-        uint32_t cur_base = 0, q_next = 0;
-        auto fetch = [&](uint32_t j, float4 &a, float2 &b, float &st) {
-            if (j < n) { a = qld(&in.ray_a[base + j]); b = load_ray_b(in, base + j, f, segment); if (sc.has_medium) st = load_state(in, base + j, segment).w; }
+        auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float &st) {
+            if (lane < b_n) { a = qld(&in.ray_a[b_base + lane]); b = load_ray_b(in, b_base + lane, f, segment); if (sc.has_medium) st = load_state(in, b_base + lane, segment).w; }
         };
-        fetch(lane, ca, cb, cs); fetch(64u + lane, na, nb, ns);
+        uint32_t c_n = 0, c_pos = 0, c_base = 0, n_n = 0, n_base = 0;
+        if (bs.next(c_base, c_n)) fetch(c_base, c_n, ca, cb, cs); else c_n = 0;
+        if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
+        // parked rays are packed densely into the park regions of this wave's queues, one region after the other: a region
+        // (q.cap + 64 entries) is closed when the next round's <= 64 entries might not fit; the wave's queues hold at most
+        // q.cap rays each, so the regions cannot run out
+        uint32_t park_q = q_first, park_n = 0;
         const uint32_t IDLE = 0xffffffffu;
         uint32_t slot = IDLE, cur = REF_DONE, path_id = 0, best_obj = MISS, best_prim = 0, deferred_obj = 0;
         float best_t = TMAX; bool have = false, deferred = false;
         V3 wo = mk(0, 0, 0), wd = wo, inv = wo;
         LdsStack st{my_stack, 0};
-        uint32_t park_n = 0;                                            // rays handed over to k_blas so far (wave-uniform)
         for (;;) {
             const unsigned long long idle_mask = __ballot(slot == IDLE);
             const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-            if (q_next < n) {
+            if (c_pos < c_n) {
                 if (n_idle >= TLAS_REFILL_MIN) {
-                    const uint32_t take = min(n_idle, min(n, cur_base + 64u) - q_next);
+                    const uint32_t take = min(n_idle, c_n - c_pos);
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-                    const uint32_t src = (q_next - cur_base) + rank;
+                    const uint32_t src = c_pos + rank;
                     const int sel = (int)((src & 63u) << 2);
                     float4 ra; float2 rb;
                     ra.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(ca.x)));
@@ -969,22 +1039,22 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                     rb.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(cb.y)));
                     const float rs = sc.has_medium ? __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(cs))) : 0.f;
                     if (slot == IDLE && rank < take) {
-                        slot = q_next + rank;
+                        slot = c_base + src;                            // absolute slot of the ray (its queue may not be the open one later)
                         const Ray r = make_ray(ra, rb, f, segment);
                         wo = r.o; wd = r.d;
                         inv = mk(fdiv(1.f, wd.x), fdiv(1.f, wd.y), fdiv(1.f, wd.z));
-                        path_id = __float_as_uint(rs);
+                        path_id = segment == 0 ? slot : __float_as_uint(rs);   // a camera path's home slot is its slot (load_state)
                         cur = sc.tlas_root; st.sp = 0;
                         have = false; best_t = TMAX; best_obj = MISS; best_prim = 0; deferred = false; deferred_obj = 0;
                     }
-                    q_next += take;
-                    if (q_next == cur_base + 64u && q_next < n) {      // cur is used up: nxt becomes cur, read 64 further ahead
-                        ca = na; cb = nb; cs = ns; cur_base += 64u;
-                        fetch(cur_base + 64u + lane, na, nb, ns);
+                    c_pos += take;
+                    if (c_pos == c_n) {       // block used up: the one in flight becomes current, the following one is requested
+                        ca = na; cb = nb; cs = ns; c_n = n_n; c_base = n_base; c_pos = 0;
+                        if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
                     }
                 }
             } else if (n_idle == 64u) {
-                break;                                                  // queue empty and every lane has retired its ray
+                break;                                                  // stream used up and every lane has retired its ray
             }
 
             // ---- one round: node steps (the wave stops once no more than a quarter of its busy lanes still walk), then objects
@@ -994,6 +1064,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                 const bool walking = busy && !(cur & REF_LEAF);
                 const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
                 if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
+                TS_COUNT(4, slot != IDLE);                              // debug builds: busy lanes per node-loop iteration
                 if (walking) {
                     TS_TICK(0);
                     cur = pair_step(sc.tlas, cur, wo, inv, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
@@ -1020,23 +1091,30 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
 
             // ---- retire the rays that are out of tree
             const bool done = slot != IDLE && cur == REF_DONE;
-            if (done && !deferred) qst(&hits[base + slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
-            if (PARK) {          // dense append to the wave's parked queue: the world ray and what the TLAS walk found so far
+            if (done && !deferred) qst(&hits[slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
+            if (PARK) {          // dense append to a park region: the world ray and what the TLAS walk found so far
                 const unsigned long long pmask = __ballot(done && deferred);
                 if (pmask) {
+                    if (park_n + 64u > park.stride) {                   // close this region, go on in the next
+                        if (lane == 0) park.pcount[park_q] = park_n;
+                        park_q++; park_n = 0;
+                    }
                     const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
                     if (done && deferred) {
-                        const uint32_t e = base + park_n + prank;
+                        const uint32_t e = park_q * park.stride + park_n + prank;
                         qst(&park.ray_a[e], make_float4(wo.x, wo.y, wo.z, wd.x));
                         qst(&park.ray_b[e], make_float2(wd.y, wd.z));
-                        qst(&park.meta[e], make_float4(__uint_as_float(base + slot), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
+                        qst(&park.meta[e], make_float4(__uint_as_float(slot), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
                     }
                     park_n += (uint32_t)__popcll(pmask);
                 }
             }
             if (done) slot = IDLE;
         }
-        if (PARK && lane == 0) park.pcount[w] = park_n;
+        if (PARK) {      // every queue of this wave's range gets a count: the filled regions theirs, the others zero
+            if (lane == 0) park.pcount[park_q] = park_n;
+            if (q_first + lane < q_last && q_first + lane > park_q) park.pcount[q_first + lane] = 0u;
+        }
         TS_END();
         return;
     }
@@ -1108,19 +1186,23 @@ void k_extend_tlas_park(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hit
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_BLAS_WAVES, 8)))
 void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
-    const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
-    if (w >= q.n_waves) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t q_first, q_last;
+    stream_range(wave_index(), q.n_waves, gridDim.x * (WB / 64), q_first, q_last);
+    if (q_first >= q_last) return;
     TS_BEGIN();
-    const uint32_t n = park.pcount[w];
-    if (lane == 0 && n) park.ptotal[w] += n;                         // statistics (fw_stats.parked_rays): wave-private, no atomics
-    const uint32_t base = w * q.cap;
+    BlockStream bs;
+    bs.init(park.pcount, q_first, q_last, park.stride, lane);
+    if (q_first + lane < q_last && bs.cnt) park.ptotal[q_first + lane] += bs.cnt;   // statistics (fw_stats.parked_rays): one writer per queue
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     float4 ca = make_float4(0, 0, 0, 0), na = ca, cm = ca, nm = ca; float2 cb = make_float2(0, 0), nb = cb;
-    auto fetch = [&](uint32_t j, float4 &a, float2 &b, float4 &m) {
-        if (j < n) { a = qld(&park.ray_a[base + j]); b = qld(&park.ray_b[base + j]); m = qld(&park.meta[base + j]); }
+    auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float4 &m) {
+        if (lane < b_n) { a = qld(&park.ray_a[b_base + lane]); b = qld(&park.ray_b[b_base + lane]); m = qld(&park.meta[b_base + lane]); }
     };
-    fetch(lane, ca, cb, cm); fetch(64u + lane, na, nb, nm);
-    uint32_t cur_base = 0, q_next = 0;
+    // two blocks of the stream in registers: `cur` is being handed out (c_pos of c_n taken), `nxt` is in flight
+    uint32_t c_n = 0, c_pos = 0, n_n = 0, bb = 0;
+    if (bs.next(bb, c_n)) fetch(bb, c_n, ca, cb, cm); else c_n = 0;
+    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
     bool act = false, have = false;
     uint32_t slot = 0, obj = 0, tri_base = 0, bcode = MISS, mtri = 0, cur = REF_DONE;
     float bt = TMAX, mbest = TMAX;
@@ -1130,11 +1212,11 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
     for (;;) {
         const unsigned long long idle_mask = __ballot(!act);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-        if (q_next < n) {
+        if (c_pos < c_n) {
             if (n_idle >= BLAS_REFILL_MIN) {
-                const uint32_t take = min(n_idle, min(n, cur_base + 64u) - q_next);
+                const uint32_t take = min(n_idle, c_n - c_pos);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-                const int sel = (int)((((q_next - cur_base) + rank) & 63u) << 2);
+                const int sel = (int)(((c_pos + rank) & 63u) << 2);
                 auto bp = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(v))); };
                 const float4 ra = make_float4(bp(ca.x), bp(ca.y), bp(ca.z), bp(ca.w));
                 const float2 rb = make_float2(bp(cb.x), bp(cb.y));
@@ -1148,10 +1230,13 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
                     tri_base = o.aux1; cur = o.aux0; st.sp = 0;
                     have = false; mbest = TMAX; mtri = 0; act = true;
                 }
-                q_next += take;
-                if (q_next == cur_base + 64u && q_next < n) { ca = na; cb = nb; cm = nm; cur_base += 64u; fetch(cur_base + 64u + lane, na, nb, nm); }
+                c_pos += take;
+                if (c_pos == c_n) {      // block used up: the one in flight becomes current, the following one is requested
+                    ca = na; cb = nb; cm = nm; c_n = n_n; c_pos = 0;
+                    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+                }
             }
-        } else if (n_idle == 64u) break;
+        } else if (n_idle == 64u) break;                                // stream used up and every lane has retired its ray
 
         const uint32_t n_act = (uint32_t)__popcll(__ballot(act));
         for (;;) {   // node steps; the wave stops once no more than half of its busy lanes still walk (the others test their
@@ -1160,11 +1245,13 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
             const bool walking = act && !(cur & REF_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
+            TS_COUNT(0, act);                                           // debug builds: busy lanes per node-loop iteration
             if (walking) {
                 TS_TICK(4);
                 cur = pair_step(sc.blas, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
             }
         }
+        TS_COUNT(2, act);                                               // busy lanes per round
         if (act && (cur & REF_LEAF)) {
             if (cur != REF_DONE) {
                 const uint32_t item = cur & NODE_MASK;
@@ -1186,6 +1273,204 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
         }
     }
     TS_END();
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4'  k_blas_lds: the same walks with the WHOLE BLAS resident in LDS.
+//
+// k_blas is bound by its node fetches: every step gathers 64 bytes per lane from L2 (suzanne: 92 % L2 hits, 52 % of the
+// wave time in s_waitcnt, and raising the lane utilisation from 55 to 80 % by streaming queues changed nothing).  MI355X has
+// 160 KB of LDS per CU: a mesh of up to ~1 500 triangles (suzanne: 967 pair nodes = 62 KB) fits next to the traversal
+// stacks of sixteen waves.  One 1024-thread workgroup per CU, persistent: it copies the pair nodes into LDS once per launch
+// and its sixteen waves then walk the parked queues of the workgroup's share, taking the next queue from a counter in LDS
+// whenever their stream runs dry (BlockStream, dynamic mode) — so the walks read nodes with ds_read_b128 (~100 cycles)
+// instead of global loads, the waves of a workgroup balance themselves, and a wave's rays refill across queue boundaries.
+// Stacks are 16-bit (LdsStack16).  Same arithmetic, same tie rules: the bits do not change.  The host launches it only
+// when nodes + stacks fit (launch_extend); bigger meshes keep k_blas.
+// Dynamic LDS: [pair nodes: 4 float4 each][16 stacks: levels x 64 x u16][queue counter].
+// ------------------------------------------------------------------------------------------------
+constexpr int LDS_WAVES = 16;                      // waves per workgroup of the LDS-resident walks
+template <bool LDS_TRIS>
+__global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q,
+                                                             uint32_t n_nodes, uint32_t n_tris, uint32_t levels) {
+    extern __shared__ float4 lds_nodes[];
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    for (uint32_t k = threadIdx.x; k < n_nodes * 4u; k += LDS_WAVES * 64) lds_nodes[k] = sc.blas[k];
+    float4 *lds_tris = lds_nodes + (size_t)n_nodes * 4u;              // LDS_TRIS: the triangles too (3 float4 each), behind the nodes
+    if (LDS_TRIS) for (uint32_t k = threadIdx.x; k < n_tris * 3u; k += LDS_WAVES * 64) lds_tris[k] = sc.tri[k];
+    uint16_t *stacks = reinterpret_cast<uint16_t *>(lds_tris + (LDS_TRIS ? (size_t)n_tris * 3u : 0u));
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(stacks + (size_t)LDS_WAVES * levels * 64u);
+    // this workgroup's share: the queues blockIdx.x + k * gridDim.x, k = 0 .. n_k - 1 — INTERLEAVED over the workgroups:
+    // neighbouring queues hold neighbouring pixels, and a run of them is several times heavier where it covers the mesh.
+    // Wave i starts with k = i, further k come from the counter in LDS.
+    const uint32_t n_k = (q.n_waves + gridDim.x - 1u - blockIdx.x) / gridDim.x;
+    if (threadIdx.x == 0) *ctr = 0u;
+    __syncthreads();
+    const uint32_t k_first = min(wib, n_k), k_last = min(k_first + 1u, n_k);
+    BlockStream bs;
+    bs.init(park.pcount, k_first, k_last, park.stride, lane, blockIdx.x, gridDim.x);
+    bs.init_dynamic(ctr, LDS_WAVES, n_k);
+    if (k_first < k_last && lane == 0 && bs.cnt) park.ptotal[blockIdx.x + k_first * gridDim.x] += bs.cnt;
+    bs.ptotal = park.ptotal;
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    float4 ca = make_float4(0, 0, 0, 0), na = ca, cm = ca, nm = ca; float2 cb = make_float2(0, 0), nb = cb;
+    auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float4 &m) {
+        if (lane < b_n) { a = qld(&park.ray_a[b_base + lane]); b = qld(&park.ray_b[b_base + lane]); m = qld(&park.meta[b_base + lane]); }
+    };
+    uint32_t c_n = 0, c_pos = 0, n_n = 0, bb = 0;
+    if (bs.next(bb, c_n)) fetch(bb, c_n, ca, cb, cm); else c_n = 0;
+    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+    bool act = false, have = false;
+    uint32_t slot = 0, obj = 0, tri_base = 0, bcode = MISS, mtri = 0, cur = REF_DONE;
+    float bt = TMAX, mbest = TMAX;
+    V3 ro = mk(0, 0, 0), inv = ro;
+    TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
+    LdsStack16 st{stacks + (size_t)wib * levels * 64u + lane, 0};
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(!act);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (c_pos < c_n) {
+            if (n_idle >= BLAS_REFILL_MIN) {
+                const uint32_t take = min(n_idle, c_n - c_pos);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                const int sel = (int)(((c_pos + rank) & 63u) << 2);
+                auto bp = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(v))); };
+                const float4 ra = make_float4(bp(ca.x), bp(ca.y), bp(ca.z), bp(ca.w));
+                const float2 rb = make_float2(bp(cb.x), bp(cb.y));
+                const float4 me = make_float4(bp(cm.x), bp(cm.y), bp(cm.z), bp(cm.w));
+                if (!act && rank < take) {
+                    slot = __float_as_uint(me.x); obj = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
+                    Obj o = load_obj(sc.obj, obj);
+                    Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
+                    ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                    tr = make_triray(r);
+                    tri_base = o.aux1; cur = o.aux0; st.sp = 0;
+                    have = false; mbest = TMAX; mtri = 0; act = true;
+                }
+                c_pos += take;
+                if (c_pos == c_n) {
+                    ca = na; cb = nb; cm = nm; c_n = n_n; c_pos = 0;
+                    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+                }
+            }
+        } else if (n_idle == 64u) break;
+
+        const uint32_t n_act = (uint32_t)__popcll(__ballot(act));
+        for (;;) {
+            const bool walking = act && !(cur & REF_LEAF);
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+            if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
+            if (walking) cur = pair_step(lds_nodes, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
+        }
+        if (act && (cur & REF_LEAF)) {
+            if (cur != REF_DONE) {
+                const uint32_t item = cur & NODE_MASK;
+                cur = st.sp ? st.pop() : REF_DONE;
+                const float4 *tp = (LDS_TRIS ? lds_tris : sc.tri) + 3 * (size_t)(tri_base + item);
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, b0, b1, b2;
+                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, TMIN, TMAX, t, b0, b1, b2)) {
+                    if (!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) { have = true; mbest = t; mtri = item; }
+                }
+            }
+            if (cur == REF_DONE) {
+                const uint32_t bobj = bcode == MISS ? MISS : (bcode >> sc.prim_bits);
+                if (have && (bobj == MISS || mbest < bt || (mbest == bt && sc.obj_rank[obj] > sc.obj_rank[bobj]))) { bt = mbest; bcode = (obj << sc.prim_bits) | mtri; }
+                qst(&hits[slot], make_float2(bt, __uint_as_float(bcode)));
+                act = false;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2'  k_extend_tlas_lds: the TLAS walk of scenes without meshes (k_extend_tlas) with the whole TLAS resident in LDS —
+// part2's 1 408 pair nodes are 90 KB.  Same organisation as k_blas_lds: one persistent 1024-thread workgroup per CU, nodes
+// copied into LDS once per launch, 16-bit stacks, queues handed out dynamically inside the workgroup and streamed.  Object
+// records stay in L2 (a ray tests ~1.5 objects for ~8 node visits).  Same tests, tie rules and culling: same bits.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q,
+                                                                    int segment, uint32_t n_nodes, uint32_t levels) {
+    extern __shared__ float4 lds_nodes[];
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
+    for (uint32_t k = threadIdx.x; k < n_nodes * 4u; k += LDS_WAVES * 64) lds_nodes[k] = sc.tlas[k];
+    uint16_t *stacks = reinterpret_cast<uint16_t *>(lds_nodes + (size_t)n_nodes * 4u);
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(stacks + (size_t)LDS_WAVES * levels * 64u);
+    const uint32_t n_k = (q.n_waves + gridDim.x - 1u - blockIdx.x) / gridDim.x;     // queues blockIdx.x + k * gridDim.x (k_blas_lds)
+    if (threadIdx.x == 0) *ctr = 0u;
+    __syncthreads();
+    const uint32_t k_first = min(wib, n_k), k_last = min(k_first + 1u, n_k);
+    BlockStream bs;
+    bs.init(q.wcount + (size_t)segment * q.n_waves, k_first, k_last, q.cap, lane, blockIdx.x, gridDim.x);
+    bs.init_dynamic(ctr, LDS_WAVES, n_k);
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    float4 ca = make_float4(0, 0, 0, 0), na = ca; float2 cb = make_float2(0, 0), nb = cb; float cs = 0.f, ns = 0.f;
+    auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float &st) {
+        if (lane < b_n) { a = qld(&in.ray_a[b_base + lane]); b = load_ray_b(in, b_base + lane, f, segment); if (sc.has_medium) st = load_state(in, b_base + lane, segment).w; }
+    };
+    uint32_t c_n = 0, c_pos = 0, c_base = 0, n_n = 0, n_base = 0;
+    if (bs.next(c_base, c_n)) fetch(c_base, c_n, ca, cb, cs); else c_n = 0;
+    if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
+    const uint32_t IDLE = 0xffffffffu;
+    uint32_t slot = IDLE, cur = REF_DONE, path_id = 0, best_obj = MISS, best_prim = 0;
+    float best_t = TMAX; bool have = false;
+    V3 wo = mk(0, 0, 0), wd = wo, inv = wo;
+    LdsStack16 st{stacks + (size_t)wib * levels * 64u + lane, 0};
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(slot == IDLE);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (c_pos < c_n) {
+            if (n_idle >= TLAS_REFILL_MIN) {
+                const uint32_t take = min(n_idle, c_n - c_pos);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                const uint32_t src = c_pos + rank;
+                const int sel = (int)((src & 63u) << 2);
+                auto bp = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(v))); };
+                const float4 ra = make_float4(bp(ca.x), bp(ca.y), bp(ca.z), bp(ca.w));
+                const float2 rb = make_float2(bp(cb.x), bp(cb.y));
+                const float rs = sc.has_medium ? bp(cs) : 0.f;
+                if (slot == IDLE && rank < take) {
+                    slot = c_base + src;
+                    const Ray r = make_ray(ra, rb, f, segment);
+                    wo = r.o; wd = r.d;
+                    inv = mk(fdiv(1.f, wd.x), fdiv(1.f, wd.y), fdiv(1.f, wd.z));
+                    path_id = __float_as_uint(rs);
+                    cur = sc.tlas_root; st.sp = 0;
+                    have = false; best_t = TMAX; best_obj = MISS; best_prim = 0;
+                }
+                c_pos += take;
+                if (c_pos == c_n) {
+                    ca = na; cb = nb; cs = ns; c_n = n_n; c_base = n_base; c_pos = 0;
+                    if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
+                }
+            }
+        } else if (n_idle == 64u) break;
+
+        const bool busy = slot != IDLE && cur != REF_DONE;
+        const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
+        for (;;) {
+            const bool walking = busy && !(cur & REF_LEAF);
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+            if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
+            if (walking) cur = pair_step(lds_nodes, cur, wo, inv, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
+        }
+        if (busy && (cur & REF_LEAF) && cur != REF_DONE) {
+            const uint32_t item = cur & NODE_MASK;
+            cur = st.sp ? st.pop() : REF_DONE;
+            Obj o = load_obj_for_hit(sc.obj, item);
+            const bool gated_out = (obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)item], sc.obj_gate[2 * (size_t)item + 1], wo, inv, TMIN, TMAX);
+            if (!gated_out) {
+                RngKey key{0, 0, 0};
+                if (sc.has_medium) key = key_of(f, path_id);
+                float t; uint32_t prim;
+                if (hit_object(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)) {   // no meshes in these scenes: no BLAS stack
+                    if (!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = item; best_prim = prim; }
+                }
+            }
+        }
+        const bool done = slot != IDLE && cur == REF_DONE;
+        if (done) { qst(&hits[slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits)); slot = IDLE; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1744,12 +2029,42 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     int levels = tl + c.blas_depth + 1;
     size_t lds = (size_t)levels * WB * sizeof(uint32_t) + (use_bvh && c.has_mesh ? 5 * DEFER_CAP * sizeof(uint32_t) : 0);
     dim3 eg = wave_grid(c);
+    // the refilling walks run on fewer physical waves, each streaming several queues (BlockStream); the scan of a small TLAS
+    // keeps one wave per queue (uniform work, nothing to refill)
+    const uint32_t n_stream = std::min<uint32_t>(c.q.n_waves, std::max<uint32_t>((uint32_t)c.stream_waves, (c.q.n_waves + 63u) / 64u));
+    const dim3 sg((n_stream + WB / 64 - 1) / (WB / 64));
     if (use_bvh && c.tlas_refill && c.has_mesh) {
         // TLAS walk that parks mesh rays in HBM, then their BLAS walks; a medium around a mesh still walks it in place (blas levels)
-        hipLaunchKernelGGL(k_extend_tlas_park, eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
-        hipLaunchKernelGGL(k_blas, eg, dim3(WB), (size_t)(c.blas_depth + 1) * WB * sizeof(uint32_t), c.stream, sc, park, hits, c.q);
+        hipLaunchKernelGGL(k_extend_tlas_park, sc.n_objects <= TLAS_SCAN_MAX ? eg : sg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
+        // the whole BLAS in LDS when it fits next to sixteen 16-bit stacks (k_blas_lds), else node fetches from L2 (k_blas)
+        const uint32_t bl = (uint32_t)c.blas_depth + 1u;
+        const size_t lds_blas = (size_t)c.blas_pair_nodes * 64 + (size_t)LDS_WAVES * bl * 64 * 2 + 16, lds_tris = (size_t)c.n_tris * 48;
+        if (c.lds_trees && c.blas_pair_nodes > 0 && c.blas_pair_nodes < 32768u && c.max_tris < 32768u && lds_blas <= LDS_TREE_LIMIT) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                attr_set = true;
+            }
+            const dim3 lg(std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES));
+            if (lds_blas + lds_tris <= LDS_TREE_LIMIT && !c.no_lds_tris)      // the triangles too, when they fit as well
+                hipLaunchKernelGGL(k_blas_lds<true>, lg, dim3(LDS_WAVES * 64), lds_blas + lds_tris, c.stream, sc, park, hits, c.q, c.blas_pair_nodes, c.n_tris, bl);
+            else
+                hipLaunchKernelGGL(k_blas_lds<false>, lg, dim3(LDS_WAVES * 64), lds_blas, c.stream, sc, park, hits, c.q, c.blas_pair_nodes, c.n_tris, bl);
+        }
+        else hipLaunchKernelGGL(k_blas, sg, dim3(WB), (size_t)(c.blas_depth + 1) * WB * sizeof(uint32_t), c.stream, sc, park, hits, c.q);
     }
-    else if (use_bvh && c.tlas_refill) hipLaunchKernelGGL(k_extend_tlas, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+    else if (use_bvh && c.tlas_refill) {
+        // scenes without meshes: the whole TLAS in LDS when it fits next to sixteen 16-bit stacks
+        const size_t lds_tlas = (size_t)c.tlas_pair_nodes * 64 + (size_t)LDS_WAVES * (uint32_t)tl * 64 * 2 + 16;
+        if (c.lds_trees && !c.has_mesh && sc.n_objects > TLAS_SCAN_MAX && c.tlas_pair_nodes < 32768u && sc.n_objects < 32768u && lds_tlas <= LDS_TREE_LIMIT) {
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT); attr_set = true; }
+            hipLaunchKernelGGL(k_extend_tlas_lds, dim3(std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES)), dim3(LDS_WAVES * 64), lds_tlas, c.stream,
+                               sc, f, in, hits, c.q, segment, c.tlas_pair_nodes, (uint32_t)tl);
+        }
+        else hipLaunchKernelGGL(k_extend_tlas, sc.n_objects <= TLAS_SCAN_MAX ? eg : sg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+    }
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }

@@ -325,6 +325,7 @@ struct fw_scene {
     fw::DScene d{};
     DevBuf data;   // every scene array in one allocation (sections 256-byte aligned)
     uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mat = 0, n_tex = 0;
+    uint32_t blas_pair_nodes = 0, tlas_pair_nodes = 0, max_tris = 0, n_tris = 0;
     bool hdr_env = false;
     ~fw_scene() {
         data.release();
@@ -706,6 +707,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     sc->hdr_env = e.kind == FW_ENV_HDR;
     sc->tlas_nodes = ref_tlas_nodes; sc->blas_nodes = fl.ref_blas_nodes;   // reported: the reference topology (bvh.rs)
     sc->tlas_depth = tlas_p.depth; sc->blas_depth = fl.blas_depth;
+    sc->blas_pair_nodes = fl.blas.count(); sc->tlas_pair_nodes = tlas_p.count(); sc->max_tris = fl.max_tris; sc->n_tris = (uint32_t)(fl.tri.size() / 12);
     sc->n_mat = desc->n_materials; sc->n_tex = desc->n_textures;
     *out = sc;
     return FW_OK;
@@ -807,7 +809,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         need(L.sample_rad, (size_t)cap * 16);                 // indexed by home slot
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
         if (park_meshes) {     // rays handed from k_extend_tlas_park to k_blas: 40 B per slot
-            need(L.park_a, (size_t)cap * 16); need(L.park_b, (size_t)cap * 8); need(L.park_m, (size_t)cap * 16); need(L.pcount, (size_t)q.n_waves * 8);   // pcount[n_waves] + ptotal[n_waves]
+            const size_t pcap = (size_t)(q.cap + 64u) * q.n_waves;     // park regions: q.cap + 64 entries per queue (DPark.stride)
+            need(L.park_a, pcap * 16); need(L.park_b, pcap * 8); need(L.park_m, pcap * 16); need(L.pcount, (size_t)q.n_waves * 8);   // pcount[n_waves] + ptotal[n_waves]
         }
         if (!rc && !L.stream && n_lanes > 1) HIPCHK(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
     }
@@ -848,6 +851,17 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.lds_tables = getenv("FIREWORK_NO_LDS_TABLES") == nullptr;
     cfg.has_mesh = sc->d.has_mesh != 0;
     cfg.tlas_refill = tlas_refill;
+    // physical waves of the refilling walks that fetch their nodes from L2: one per queue.  Fewer waves that stream several
+    // queues each (FIREWORK_STREAM_WAVES=n) raise the lane utilisation of the node loop (suzanne's k_blas: 55 -> 80 % busy
+    // lanes, 29 % fewer wave-iterations) and LOSE time: 10.2 -> 15.4 ms at one round of resident waves, 11.7 ms with queues
+    // handed out dynamically — those kernels are bound by the node gathers, not by instruction issue, and statically dealt
+    // runs of queues are unevenly loaded.  The LDS-resident walks (k_blas_lds) do stream, dynamically, inside a workgroup.
+    cfg.stream_waves = (int)q.n_waves;
+    cfg.n_cus = sc->n_cus;
+    cfg.blas_pair_nodes = sc->blas_pair_nodes; cfg.tlas_pair_nodes = sc->tlas_pair_nodes; cfg.max_tris = sc->max_tris; cfg.n_tris = sc->n_tris;
+    cfg.no_lds_tris = getenv("FIREWORK_NO_LDS_TRIS") != nullptr;
+    cfg.lds_trees = getenv("FIREWORK_NO_LDS_TREES") == nullptr;
+    if (const char *e = getenv("FIREWORK_STREAM_WAVES")) { long v = atol(e); if (v > 0) cfg.stream_waves = (int)std::min<long>(v, 1 << 24); }
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
@@ -905,7 +919,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         for (int k = 0; k < 2; k++) buf[k] = {(float4 *)L.ray_a[k].p, (float2 *)L.ray_b[k].p, (float4 *)L.state[k].p};
         float2 *hits = (float2 *)L.hits.p;
         float4 *srad = (float4 *)L.sample_rad.p, *accum = (float4 *)ws->accum.p;
-        const fw::DPark park{(float4 *)L.park_a.p, (float2 *)L.park_b.p, (float4 *)L.park_m.p, (uint32_t *)L.pcount.p,
+        const fw::DPark park{(float4 *)L.park_a.p, (float2 *)L.park_b.p, (float4 *)L.park_m.p, q.cap + 64u, (uint32_t *)L.pcount.p,
                              park_meshes ? (uint32_t *)L.pcount.p + q.n_waves : nullptr};
         if (park_meshes) HIPCHK(hipMemsetAsync(park.ptotal, 0, (size_t)q.n_waves * 4, ls));
         int cur = 0;
