@@ -155,8 +155,6 @@ struct LaunchCfg {
     uint32_t n_mat, n_tex;        // table sizes (for the LDS-resident copy in k_shade)
     bool lds_tables;              // stage small scene tables in LDS (debug switch: FIREWORK_NO_LDS_TABLES)
     bool has_mesh;
-    int stream_waves;     // physical waves of the refilling walks (k_extend_tlas*, k_blas): each streams n_waves / stream_waves
-                          // consecutive wave queues back to back, so that only its LAST rays run in a thinning wave
     int n_cus;
     uint32_t blas_pair_nodes, tlas_pair_nodes, max_tris, n_tris;   // n_tris: all meshes together
     bool no_lds_tris;     // A/B switch FIREWORK_NO_LDS_TRIS   // sizes of the walked trees (pair nodes) and of the biggest mesh

@@ -234,30 +234,39 @@ __device__ __forceinline__ float2 pack_hit(float t, uint32_t obj, uint32_t prim,
 
 // Wave w generates the paths  id = chunk * (n_waves*64) + w*64 + lane  (chunks of 64 consecutive pixels of
 // one sample index, dealt round-robin to the waves: coherent inside a wave, balanced across waves).
+// render.rs:172-180 + camera.rs:109-116 for one path: the camera ray of (pixel, sample).
+// (Round 2 tried to RECOMPUTE this ray in k_shade at segment 0 instead of loading it — 16 B per sample, 4.3 GB per cornell
+// frame less HBM traffic, bit-identical by construction.  It lost: k_shade 21.9 -> 23.1 ms, hdri 5.9 -> 6.4 ms, at 125
+// instead of 115 registers: the kernel is not bound by bytes alone.  Removed.)
+__device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DFrame &f, const RngKey &k) {
+    const Rcp rw = make_rcp((float)f.width), rh = make_rcp((float)f.height);
+    uint32_t py_row = (uint32_t)((float)k.pixel * f.inv_width);      // k.pixel / width without an integer division
+    int32_t px = (int32_t)(k.pixel - py_row * f.width);
+    if (px < 0) { py_row--; px += (int32_t)f.width; } else if ((uint32_t)px >= f.width) { py_row++; px -= (int32_t)f.width; }
+    uint32_t py = f.height - py_row;                                  // util.rs:31-33 Coord::from_index
+    uint4 j = draw(k, P_JITTER, 0, 0);
+    float u = fdiv((float)px + u2f(j.x), rw);                         // render.rs:178
+    float v = fdiv((float)py + u2f(j.y), rh);                         // render.rs:179
+    // camera.rs:109-116 — the disk sample is drawn even when the aperture is 0
+    V3 rd = cam.lens_radius * random_in_unit_disk(k);
+    V3 cu = ld3(cam.u), cv = ld3(cam.v), pos = ld3(cam.position);
+    V3 offset = cu * rd.x + cv * rd.y;
+    V3 o = pos + offset;
+    V3 d = ld3(cam.lower_left) + u * ld3(cam.horizontal) + v * ld3(cam.vertical) - pos - offset;
+    return Ray{o, d};
+}
+
 __global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out, float4 *__restrict__ sample_rad, DQueue q, uint32_t n_paths) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     if (w >= q.n_waves) return;
-    const Rcp rw = make_rcp((float)f.width), rh = make_rcp((float)f.height);
     uint32_t produced = 0;
     for (uint32_t chunk = 0;; chunk++) {
         uint32_t id0 = chunk * (q.n_waves * 64u) + w * 64u;
         if (id0 >= n_paths) break;
         uint32_t i = id0 + lane;
         if (i < n_paths) {
-            RngKey k = key_of_linear(f, i);
-            uint32_t py_row = (uint32_t)((float)k.pixel * f.inv_width);      // k.pixel / width without an integer division
-            int32_t px = (int32_t)(k.pixel - py_row * f.width);
-            if (px < 0) { py_row--; px += (int32_t)f.width; } else if ((uint32_t)px >= f.width) { py_row++; px -= (int32_t)f.width; }
-            uint32_t py = f.height - py_row;                                  // util.rs:31-33 Coord::from_index
-            uint4 j = draw(k, P_JITTER, 0, 0);
-            float u = fdiv((float)px + u2f(j.x), rw);                         // render.rs:178
-            float v = fdiv((float)py + u2f(j.y), rh);                         // render.rs:179
-            // camera.rs:109-116 — the disk sample is drawn even when the aperture is 0
-            V3 rd = cam.lens_radius * random_in_unit_disk(k);
-            V3 cu = ld3(cam.u), cv = ld3(cam.v), pos = ld3(cam.position);
-            V3 offset = cu * rd.x + cv * rd.y;
-            V3 o = pos + offset;
-            V3 d = ld3(cam.lower_left) + u * ld3(cam.horizontal) + v * ld3(cam.vertical) - pos - offset;
+            const Ray r = camera_ray(cam, f, key_of_linear(f, i));
+            const V3 o = r.o, d = r.d;
             uint32_t slot = w * q.cap + chunk * 64u + lane;
             if (f.pinhole0) qst(&out.ray_a[slot], make_float4(d.x, d.y, d.z, 0.f));
             else {
@@ -717,11 +726,14 @@ static_assert(FW_BLAS_WALK_NUM > FW_BLAS_WALK_DEN, "the walk must continue while
 constexpr uint32_t BLAS_WALK_NUM = FW_BLAS_WALK_NUM, BLAS_WALK_DEN = FW_BLAS_WALK_DEN;   // node walking stops when walkers * NUM <= busy lanes * DEN
 static_assert(FW_WB == 64, "the parked-ray list and the wave-private queues assume single-wave workgroups");
 
-// A physical wave of the refilling walks streams the entries of SEVERAL consecutive wave queues, back to back, as blocks of
-// <= 64 (one register read-ahead buffer each).  With one queue per wave the busy lanes of k_blas averaged 55 % in the node
-// loop (tools/trav_stats.py, suzanne): every queue ends with a few long walks in an emptying wave, and a queue holds only a
-// few generations of 64 rays.  Streaming G queues leaves one such tail per G queues.  Which physical wave walks a ray does
-// not matter: every result is written to the ray's own slot.
+// The LDS-resident walks (k_blas_lds, k_extend_tlas_lds) read the entries of SEVERAL wave queues as one stream of blocks of
+// <= 64 (one register read-ahead buffer each): a wave that has handed out its queue takes the next one of its workgroup, so
+// rays refill across queue boundaries and only a workgroup's very last rays walk in a thinning wave.  Which physical wave
+// walks a ray does not matter: every result is written to the ray's own slot.
+// (Tried on the L2-fetching walks too — several consecutive queues per wave, statically dealt or taken from a device-wide
+// atomic: the busy lanes of suzanne's k_blas node loop rose from 55 to 80 %, wave-iterations fell 29 %, and the kernel got
+// SLOWER, 10.2 -> 15.4 / 11.7 ms: those walks are bound by their node gathers, runs of neighbouring queues are unevenly
+// loaded, and the extra registers cost a wave per SIMD.  They keep one queue per wave.)
 struct BlockStream {
     // the wave's queues are named by an index k: queue id = q_off + k * q_mul (k-ranges are dealt statically or taken from a counter)
     uint32_t q, q_end, q0;     // next index to open; end and start of this wave's static range
@@ -760,12 +772,6 @@ struct BlockStream {
         }
     }
 };
-// queues [first, last) of physical wave p when n_queues are dealt to n_phys waves in runs of G = ceil(n_queues / n_phys) <= 64
-__device__ __forceinline__ void stream_range(uint32_t p, uint32_t n_queues, uint32_t n_phys, uint32_t &first, uint32_t &last) {
-    const uint32_t G = (n_queues + n_phys - 1u) / n_phys;
-    first = min(p * G, n_queues); last = min(first + G, n_queues);
-}
-
 // Closest hit of one ray: the linear scan of scene.rs:137-149 or the TLAS walk of bvh.rs:115-151.  With DEFER a
 // ray that reaches a mesh leaf of the TLAS reports (deferred, deferred_obj) instead of entering the BLAS.
 template <bool USE_BVH, bool DEFER>
@@ -937,98 +943,33 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
         }
     };
 
-    if (USE_BVH && REFILL && sc.n_objects <= TLAS_SCAN_MAX) {
-        // ---- a TLAS of a handful of objects (suzanne: floor, light, mesh) is not walked but scanned: every lane tests every
-        // object's box (the very box and slab test its leaf has in the tree, culled against the best t like pair_step) and, where
-        // that passes, the object — with wave-uniform object indices, i.e. scalar loads and no divergence between lanes.  The
-        // tree walk reaches an object iff its own box passes (its ancestors' boxes are supersets, and the slab arithmetic is
-        // monotone), and ties are decided by rank, not by order, so the result is the tree walk's bit for bit
-        // (suzanne's k_extend_tlas_park: 3.5 of the 11 ms went into walking three objects).
-        uint32_t park_n = 0;
-        float4 ra_n = make_float4(0, 0, 0, 0); float2 rb_n = make_float2(0, 0);
-        if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); }
-        for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
-            const uint32_t j = c0 + lane, i = base + j;
-            const float4 ra = ra_n; const float2 rb = rb_n;
-            if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); }
-            const bool active = j < n;
-            bool deferred = false, have = false; uint32_t deferred_obj = 0, best_obj = MISS, best_prim = 0; float best_t = TMAX;
-            Ray r{mk(0, 0, 0), mk(0, 0, 1)};
-            if (active) {
-                r = make_ray(ra, rb, f, segment);
-                RngKey key{0, 0, 0};
-                if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
-                const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
-                for (uint32_t k = 0; k < sc.n_objects; k++) {
-                    const float4 lo = sc.obj_cull[2 * (size_t)k], hi = sc.obj_cull[2 * (size_t)k + 1];   // the leaf's box in the walked tree
-                    float entry;
-                    if (!hit_aabb_entry(lo, hi, r.o, inv, TMIN, TMAX, entry) || entry > cull_bound(have ? best_t : TMAX)) continue;
-                    Obj o = load_obj(sc.obj, k);
-                    if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)k], sc.obj_gate[2 * (size_t)k + 1], r.o, inv, TMIN, TMAX)) continue;
-                    if (PARK && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = k; continue; }
-                    float t; uint32_t prim;
-                    if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
-                        if (!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = k; best_prim = prim; }
-                    }
-                }
-                if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
-            }
-            if (PARK) {
-                const unsigned long long pmask = __ballot(deferred);
-                if (pmask) {
-                    const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
-                    if (deferred) {
-                        const uint32_t e = w * park.stride + park_n + prank;
-                        qst(&park.ray_a[e], make_float4(r.o.x, r.o.y, r.o.z, r.d.x));
-                        qst(&park.ray_b[e], make_float2(r.d.y, r.d.z));
-                        qst(&park.meta[e], make_float4(__uint_as_float(i), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
-                    }
-                    park_n += (uint32_t)__popcll(pmask);
-                }
-            }
-        }
-        if (PARK && lane == 0) park.pcount[w] = park_n;
-        TS_END();
-        return;
-    }
     if (USE_BVH && REFILL) {
         // ---- TLAS walk with in-wave refill.  The chunked loop below gives every lane one ray of a 64-ray chunk and waits
         // for the slowest: on part2 only 40 % of the lanes are still busy in an average round (tools/trav_stats.py).  Here a
         // lane that has finished its ray writes the hit record (or parks the ray for its mesh) and, once TLAS_REFILL_MIN
-        // lanes are idle, the idle lanes take the next rays of the stream.  The stream is read one block of 64 rays ahead into
-        // registers (one block being handed out through ds_bpermute, one in flight), so a refill never waits for HBM, and it
-        // runs over all the queues this physical wave was given (BlockStream), so only the wave's very last rays walk in a
-        // thinning wave.  Same tests, same tie rules, same culling as closest_hit<true>: the bits do not change.
-        // (This launch has gridDim.x PHYSICAL waves; `w` above is not a queue id here.)
-        uint32_t q_first, q_last;
-        stream_range(wave_index(), q.n_waves, gridDim.x * (WB / 64), q_first, q_last);
-        if (q_first >= q_last) { TS_END(); return; }
-        BlockStream bs;
-        bs.init(q.wcount + (size_t)segment * q.n_waves, q_first, q_last, q.cap, lane);
+        // lanes are idle, the idle lanes take the next rays of the wave's queue.  The queue is read 64 rays ahead into
+        // registers (one buffer being handed out through ds_bpermute, one in flight), so a refill never waits for HBM.
+        // Same tests, same tie rules, same culling as closest_hit<true>: the bits do not change.
         float4 ca = make_float4(0, 0, 0, 0), na = ca; float2 cb = make_float2(0, 0), nb = cb; float cs = 0.f, ns = 0.f;
-        auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float &st) {
-            if (lane < b_n) { a = qld(&in.ray_a[b_base + lane]); b = load_ray_b(in, b_base + lane, f, segment); if (sc.has_medium) st = load_state(in, b_base + lane, segment).w; }
+        uint32_t cur_base = 0, q_next = 0;
+        auto fetch = [&](uint32_t j, float4 &a, float2 &b, float &st) {
+            if (j < n) { a = qld(&in.ray_a[base + j]); b = load_ray_b(in, base + j, f, segment); if (sc.has_medium) st = load_state(in, base + j, segment).w; }
         };
-        uint32_t c_n = 0, c_pos = 0, c_base = 0, n_n = 0, n_base = 0;
-        if (bs.next(c_base, c_n)) fetch(c_base, c_n, ca, cb, cs); else c_n = 0;
-        if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
-        // parked rays are packed densely into the park regions of this wave's queues, one region after the other: a region
-        // (q.cap + 64 entries) is closed when the next round's <= 64 entries might not fit; the wave's queues hold at most
-        // q.cap rays each, so the regions cannot run out
-        uint32_t park_q = q_first, park_n = 0;
+        fetch(lane, ca, cb, cs); fetch(64u + lane, na, nb, ns);
         const uint32_t IDLE = 0xffffffffu;
         uint32_t slot = IDLE, cur = REF_DONE, path_id = 0, best_obj = MISS, best_prim = 0, deferred_obj = 0;
         float best_t = TMAX; bool have = false, deferred = false;
         V3 wo = mk(0, 0, 0), wd = wo, inv = wo;
         LdsStack st{my_stack, 0};
+        uint32_t park_n = 0;                                            // rays handed over to k_blas so far (wave-uniform)
         for (;;) {
             const unsigned long long idle_mask = __ballot(slot == IDLE);
             const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-            if (c_pos < c_n) {
+            if (q_next < n) {
                 if (n_idle >= TLAS_REFILL_MIN) {
-                    const uint32_t take = min(n_idle, c_n - c_pos);
+                    const uint32_t take = min(n_idle, min(n, cur_base + 64u) - q_next);
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-                    const uint32_t src = c_pos + rank;
+                    const uint32_t src = (q_next - cur_base) + rank;
                     const int sel = (int)((src & 63u) << 2);
                     float4 ra; float2 rb;
                     ra.x = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(ca.x)));
@@ -1039,22 +980,22 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                     rb.y = __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(cb.y)));
                     const float rs = sc.has_medium ? __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(cs))) : 0.f;
                     if (slot == IDLE && rank < take) {
-                        slot = c_base + src;                            // absolute slot of the ray (its queue may not be the open one later)
+                        slot = q_next + rank;
                         const Ray r = make_ray(ra, rb, f, segment);
                         wo = r.o; wd = r.d;
                         inv = mk(fdiv(1.f, wd.x), fdiv(1.f, wd.y), fdiv(1.f, wd.z));
-                        path_id = segment == 0 ? slot : __float_as_uint(rs);   // a camera path's home slot is its slot (load_state)
+                        path_id = __float_as_uint(rs);
                         cur = sc.tlas_root; st.sp = 0;
                         have = false; best_t = TMAX; best_obj = MISS; best_prim = 0; deferred = false; deferred_obj = 0;
                     }
-                    c_pos += take;
-                    if (c_pos == c_n) {       // block used up: the one in flight becomes current, the following one is requested
-                        ca = na; cb = nb; cs = ns; c_n = n_n; c_base = n_base; c_pos = 0;
-                        if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
+                    q_next += take;
+                    if (q_next == cur_base + 64u && q_next < n) {      // cur is used up: nxt becomes cur, read 64 further ahead
+                        ca = na; cb = nb; cs = ns; cur_base += 64u;
+                        fetch(cur_base + 64u + lane, na, nb, ns);
                     }
                 }
             } else if (n_idle == 64u) {
-                break;                                                  // stream used up and every lane has retired its ray
+                break;                                                  // queue empty and every lane has retired its ray
             }
 
             // ---- one round: node steps (the wave stops once no more than a quarter of its busy lanes still walk), then objects
@@ -1064,7 +1005,6 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                 const bool walking = busy && !(cur & REF_LEAF);
                 const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
                 if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
-                TS_COUNT(4, slot != IDLE);                              // debug builds: busy lanes per node-loop iteration
                 if (walking) {
                     TS_TICK(0);
                     cur = pair_step(sc.tlas, cur, wo, inv, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
@@ -1091,30 +1031,23 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
 
             // ---- retire the rays that are out of tree
             const bool done = slot != IDLE && cur == REF_DONE;
-            if (done && !deferred) qst(&hits[slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
-            if (PARK) {          // dense append to a park region: the world ray and what the TLAS walk found so far
+            if (done && !deferred) qst(&hits[base + slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
+            if (PARK) {          // dense append to the wave's parked queue: the world ray and what the TLAS walk found so far
                 const unsigned long long pmask = __ballot(done && deferred);
                 if (pmask) {
-                    if (park_n + 64u > park.stride) {                   // close this region, go on in the next
-                        if (lane == 0) park.pcount[park_q] = park_n;
-                        park_q++; park_n = 0;
-                    }
                     const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
                     if (done && deferred) {
-                        const uint32_t e = park_q * park.stride + park_n + prank;
+                        const uint32_t e = w * park.stride + park_n + prank;
                         qst(&park.ray_a[e], make_float4(wo.x, wo.y, wo.z, wd.x));
                         qst(&park.ray_b[e], make_float2(wd.y, wd.z));
-                        qst(&park.meta[e], make_float4(__uint_as_float(slot), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
+                        qst(&park.meta[e], make_float4(__uint_as_float(base + slot), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
                     }
                     park_n += (uint32_t)__popcll(pmask);
                 }
             }
             if (done) slot = IDLE;
         }
-        if (PARK) {      // every queue of this wave's range gets a count: the filled regions theirs, the others zero
-            if (lane == 0) park.pcount[park_q] = park_n;
-            if (q_first + lane < q_last && q_first + lane > park_q) park.pcount[q_first + lane] = 0u;
-        }
+        if (PARK && lane == 0) park.pcount[w] = park_n;
         TS_END();
         return;
     }
@@ -1153,6 +1086,75 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
     if (USE_BVH && list_n) blas_run();
     TS_END();
 }
+// ------------------------------------------------------------------------------------------------
+// K2''  k_extend_scan: scenes whose TLAS holds at most TLAS_SCAN_MAX objects (suzanne: floor, light, mesh; teapot: 4 meshes,
+// floor, light).  Its own kernel since round 2: inside the one body of all BVH entry points it shared their 96 registers
+// (5 waves per SIMD) although it only streams rays through a few wave-uniform tests and waits for HBM.
+// ------------------------------------------------------------------------------------------------
+#ifndef FW_SCAN_WAVES
+#define FW_SCAN_WAVES 6
+#endif
+template <bool PARK>
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVES, 8))) void k_extend_scan(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment,
+                                                    int tlas_levels, DPark park) {
+    const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
+    if (w >= q.n_waves) return;
+    const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w];
+    const uint32_t base = w * q.cap;
+    uint32_t *blas_stack = lds_stack + threadIdx.x + (size_t)tlas_levels * WB;   // a medium around a mesh walks its BLAS in place
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    // ---- a TLAS of a handful of objects (suzanne: floor, light, mesh) is not walked but scanned: every lane tests every
+    // object's box (the very box and slab test its leaf has in the tree, culled against the best t like pair_step) and, where
+    // that passes, the object — with wave-uniform object indices, i.e. scalar loads and no divergence between lanes.  The
+    // tree walk reaches an object iff its own box passes (its ancestors' boxes are supersets, and the slab arithmetic is
+    // monotone), and ties are decided by rank, not by order, so the result is the tree walk's bit for bit
+    // (suzanne's k_extend_tlas_park: 3.5 of the 11 ms went into walking three objects).
+    uint32_t park_n = 0;
+    float4 ra_n = make_float4(0, 0, 0, 0); float2 rb_n = make_float2(0, 0);
+    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); }
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const uint32_t j = c0 + lane, i = base + j;
+        const float4 ra = ra_n; const float2 rb = rb_n;
+        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); }
+        const bool active = j < n;
+        bool deferred = false, have = false; uint32_t deferred_obj = 0, best_obj = MISS, best_prim = 0; float best_t = TMAX;
+        Ray r{mk(0, 0, 0), mk(0, 0, 1)};
+        if (active) {
+            r = make_ray(ra, rb, f, segment);
+            RngKey key{0, 0, 0};
+            if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
+            const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+            for (uint32_t k = 0; k < sc.n_objects; k++) {
+                const float4 lo = sc.obj_cull[2 * (size_t)k], hi = sc.obj_cull[2 * (size_t)k + 1];   // the leaf's box in the walked tree
+                float entry;
+                if (!hit_aabb_entry(lo, hi, r.o, inv, TMIN, TMAX, entry) || entry > cull_bound(have ? best_t : TMAX)) continue;
+                Obj o = load_obj(sc.obj, k);
+                if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)k], sc.obj_gate[2 * (size_t)k + 1], r.o, inv, TMIN, TMAX)) continue;
+                if (PARK && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = k; continue; }
+                float t; uint32_t prim;
+                if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+                    if (!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = k; best_prim = prim; }
+                }
+            }
+            if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
+        }
+        if (PARK) {
+            const unsigned long long pmask = __ballot(deferred);
+            if (pmask) {
+                const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
+                if (deferred) {
+                    const uint32_t e = w * park.stride + park_n + prank;
+                    qst(&park.ray_a[e], make_float4(r.o.x, r.o.y, r.o.z, r.d.x));
+                    qst(&park.ray_b[e], make_float2(r.d.y, r.d.z));
+                    qst(&park.meta[e], make_float4(__uint_as_float(i), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
+                }
+                park_n += (uint32_t)__popcll(pmask);
+            }
+        }
+    }
+    if (PARK && lane == 0) park.pcount[w] = park_n;
+}
+
 // Two entry points because the register budget that pays differs.  The linear scan is VALU-issue-bound and its dependent
 // division chains want many waves: 7 per SIMD (72 VGPRs, no spills) 19.7 vs 20.2 ms at the compiler's own 73.  The BVH walk
 // waits on dependent node fetches: 5 waves (96 VGPRs, no spills) instead of 4 (104): suzanne 18.7 vs 20.6 ms, part2 14.9 vs
@@ -1186,23 +1188,19 @@ void k_extend_tlas_park(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hit
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_BLAS_WAVES, 8)))
 void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t q_first, q_last;
-    stream_range(wave_index(), q.n_waves, gridDim.x * (WB / 64), q_first, q_last);
-    if (q_first >= q_last) return;
+    const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
+    if (w >= q.n_waves) return;
     TS_BEGIN();
-    BlockStream bs;
-    bs.init(park.pcount, q_first, q_last, park.stride, lane);
-    if (q_first + lane < q_last && bs.cnt) park.ptotal[q_first + lane] += bs.cnt;   // statistics (fw_stats.parked_rays): one writer per queue
+    const uint32_t n = park.pcount[w];
+    if (lane == 0 && n) park.ptotal[w] += n;                         // statistics (fw_stats.parked_rays): wave-private, no atomics
+    const uint32_t base = w * park.stride;
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     float4 ca = make_float4(0, 0, 0, 0), na = ca, cm = ca, nm = ca; float2 cb = make_float2(0, 0), nb = cb;
-    auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float4 &m) {
-        if (lane < b_n) { a = qld(&park.ray_a[b_base + lane]); b = qld(&park.ray_b[b_base + lane]); m = qld(&park.meta[b_base + lane]); }
+    auto fetch = [&](uint32_t j, float4 &a, float2 &b, float4 &m) {
+        if (j < n) { a = qld(&park.ray_a[base + j]); b = qld(&park.ray_b[base + j]); m = qld(&park.meta[base + j]); }
     };
-    // two blocks of the stream in registers: `cur` is being handed out (c_pos of c_n taken), `nxt` is in flight
-    uint32_t c_n = 0, c_pos = 0, n_n = 0, bb = 0;
-    if (bs.next(bb, c_n)) fetch(bb, c_n, ca, cb, cm); else c_n = 0;
-    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+    fetch(lane, ca, cb, cm); fetch(64u + lane, na, nb, nm);
+    uint32_t cur_base = 0, q_next = 0;
     bool act = false, have = false;
     uint32_t slot = 0, obj = 0, tri_base = 0, bcode = MISS, mtri = 0, cur = REF_DONE;
     float bt = TMAX, mbest = TMAX;
@@ -1212,11 +1210,11 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
     for (;;) {
         const unsigned long long idle_mask = __ballot(!act);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-        if (c_pos < c_n) {
+        if (q_next < n) {
             if (n_idle >= BLAS_REFILL_MIN) {
-                const uint32_t take = min(n_idle, c_n - c_pos);
+                const uint32_t take = min(n_idle, min(n, cur_base + 64u) - q_next);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
-                const int sel = (int)(((c_pos + rank) & 63u) << 2);
+                const int sel = (int)((((q_next - cur_base) + rank) & 63u) << 2);
                 auto bp = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(sel, __float_as_int(v))); };
                 const float4 ra = make_float4(bp(ca.x), bp(ca.y), bp(ca.z), bp(ca.w));
                 const float2 rb = make_float2(bp(cb.x), bp(cb.y));
@@ -1230,13 +1228,10 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
                     tri_base = o.aux1; cur = o.aux0; st.sp = 0;
                     have = false; mbest = TMAX; mtri = 0; act = true;
                 }
-                c_pos += take;
-                if (c_pos == c_n) {      // block used up: the one in flight becomes current, the following one is requested
-                    ca = na; cb = nb; cm = nm; c_n = n_n; c_pos = 0;
-                    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
-                }
+                q_next += take;
+                if (q_next == cur_base + 64u && q_next < n) { ca = na; cb = nb; cm = nm; cur_base += 64u; fetch(cur_base + 64u + lane, na, nb, nm); }
             }
-        } else if (n_idle == 64u) break;                                // stream used up and every lane has retired its ray
+        } else if (n_idle == 64u) break;
 
         const uint32_t n_act = (uint32_t)__popcll(__ballot(act));
         for (;;) {   // node steps; the wave stops once no more than half of its busy lanes still walk (the others test their
@@ -1245,13 +1240,11 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
             const bool walking = act && !(cur & REF_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
-            TS_COUNT(0, act);                                           // debug builds: busy lanes per node-loop iteration
             if (walking) {
                 TS_TICK(4);
                 cur = pair_step(sc.blas, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
             }
         }
-        TS_COUNT(2, act);                                               // busy lanes per round
         if (act && (cur & REF_LEAF)) {
             if (cur != REF_DONE) {
                 const uint32_t item = cur & NODE_MASK;
@@ -2029,13 +2022,11 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     int levels = tl + c.blas_depth + 1;
     size_t lds = (size_t)levels * WB * sizeof(uint32_t) + (use_bvh && c.has_mesh ? 5 * DEFER_CAP * sizeof(uint32_t) : 0);
     dim3 eg = wave_grid(c);
-    // the refilling walks run on fewer physical waves, each streaming several queues (BlockStream); the scan of a small TLAS
-    // keeps one wave per queue (uniform work, nothing to refill)
-    const uint32_t n_stream = std::min<uint32_t>(c.q.n_waves, std::max<uint32_t>((uint32_t)c.stream_waves, (c.q.n_waves + 63u) / 64u));
-    const dim3 sg((n_stream + WB / 64 - 1) / (WB / 64));
+    const dim3 sg = eg;
     if (use_bvh && c.tlas_refill && c.has_mesh) {
         // TLAS walk that parks mesh rays in HBM, then their BLAS walks; a medium around a mesh still walks it in place (blas levels)
-        hipLaunchKernelGGL(k_extend_tlas_park, sc.n_objects <= TLAS_SCAN_MAX ? eg : sg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
+        if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<true>, eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park);
+        else hipLaunchKernelGGL(k_extend_tlas_park, sg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
         // the whole BLAS in LDS when it fits next to sixteen 16-bit stacks (k_blas_lds), else node fetches from L2 (k_blas)
         const uint32_t bl = (uint32_t)c.blas_depth + 1u;
         const size_t lds_blas = (size_t)c.blas_pair_nodes * 64 + (size_t)LDS_WAVES * bl * 64 * 2 + 16, lds_tris = (size_t)c.n_tris * 48;
@@ -2063,7 +2054,8 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
             hipLaunchKernelGGL(k_extend_tlas_lds, dim3(std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES)), dim3(LDS_WAVES * 64), lds_tlas, c.stream,
                                sc, f, in, hits, c.q, segment, c.tlas_pair_nodes, (uint32_t)tl);
         }
-        else hipLaunchKernelGGL(k_extend_tlas, sc.n_objects <= TLAS_SCAN_MAX ? eg : sg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+        else if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, DPark{});
+        else hipLaunchKernelGGL(k_extend_tlas, sg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     }
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);

@@ -851,17 +851,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.lds_tables = getenv("FIREWORK_NO_LDS_TABLES") == nullptr;
     cfg.has_mesh = sc->d.has_mesh != 0;
     cfg.tlas_refill = tlas_refill;
-    // physical waves of the refilling walks that fetch their nodes from L2: one per queue.  Fewer waves that stream several
-    // queues each (FIREWORK_STREAM_WAVES=n) raise the lane utilisation of the node loop (suzanne's k_blas: 55 -> 80 % busy
-    // lanes, 29 % fewer wave-iterations) and LOSE time: 10.2 -> 15.4 ms at one round of resident waves, 11.7 ms with queues
-    // handed out dynamically — those kernels are bound by the node gathers, not by instruction issue, and statically dealt
-    // runs of queues are unevenly loaded.  The LDS-resident walks (k_blas_lds) do stream, dynamically, inside a workgroup.
-    cfg.stream_waves = (int)q.n_waves;
     cfg.n_cus = sc->n_cus;
     cfg.blas_pair_nodes = sc->blas_pair_nodes; cfg.tlas_pair_nodes = sc->tlas_pair_nodes; cfg.max_tris = sc->max_tris; cfg.n_tris = sc->n_tris;
     cfg.no_lds_tris = getenv("FIREWORK_NO_LDS_TRIS") != nullptr;
     cfg.lds_trees = getenv("FIREWORK_NO_LDS_TREES") == nullptr;
-    if (const char *e = getenv("FIREWORK_STREAM_WAVES")) { long v = atol(e); if (v > 0) cfg.stream_waves = (int)std::min<long>(v, 1 << 24); }
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
