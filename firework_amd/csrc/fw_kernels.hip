@@ -1155,6 +1155,13 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVE
     if (PARK && lane == 0) park.pcount[w] = park_n;
 }
 
+// (Round 2 tried to DEFER the expensive shapes of the linear scan: cornell's two rotated boxes are 12 of a ray's 18 rectangle
+// tests and 44 % of k_extend_linear (tools/cornell_parts.py), and a bounce ray can reach each only about one time in four.
+// The scan tested the cheap shapes in line, appended the rays whose inflated world-box test passed to a wave-private LDS
+// list with a bit mask of shapes, and ran the listed rays 64 at a time with every lane busy; equal t went to the later
+// object by an explicit merge rule, so the bits were the in-order scan's (GPU tests green).  It lost: 19.2 -> 24.4 ms.  The
+// run phase reads object records per lane (vector loads and VGPR operands instead of scalar ones), the list and the second
+// copy of the shape tests cost registers (18 spills at 72), and scenes without such shapes paid 8 % for the bookkeeping.)
 // Two entry points because the register budget that pays differs.  The linear scan is VALU-issue-bound and its dependent
 // division chains want many waves: 7 per SIMD (72 VGPRs, no spills) 19.7 vs 20.2 ms at the compiler's own 73.  The BVH walk
 // waits on dependent node fetches: 5 waves (96 VGPRs, no spills) instead of 4 (104): suzanne 18.7 vs 20.6 ms, part2 14.9 vs
