@@ -766,7 +766,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     std::lock_guard<std::mutex> ws_guard(ws->mu);
 
     // ---- batches and lanes -----------------------------------------------------------------------------------
-    int n_lanes = 1;   // measured on cornell: 2-4 lanes overlap extend (VALU) with shade (HBM) for only ~3 % (63.4 -> 61.6 ms)
+    // Two batches in flight on two streams under use_bvh: the tree walks leave issue slots and HBM idle (the LDS-resident
+    // ones run 4 waves per SIMD) that the other batch's k_shade / k_extend_scan fills.  Full-size configs, interleaved on one
+    // box (tools/configs.sh): suzanne 92.2 -> 81.1 ms, random_spheres 2.0 -> 1.8, part2 2287 -> 2271; 3 or 4 lanes gain less.
+    // The linear scan stays at one batch in flight: cornell gains 4-5 % (42.2 -> 40.3 ms), hdri and volume lose 1-3 %
+    // (both of their kernels wait for HBM), and with one lane every kernel's HIP-event time is its own — what bench.py's
+    // roofline object divides by.  FIREWORK_STREAMS=n overrides.  Results do not depend on n (batches accumulate in order).
+    int n_lanes = p->use_bvh ? 2 : 1;
     if (const char *e = getenv("FIREWORK_STREAMS")) { int v = atoi(e); if (v >= 1) n_lanes = std::min(v, (int)Workspace::MAX_LANES); }
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, p->samples);
     uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch() / (uint32_t)n_lanes;

@@ -1,6 +1,5 @@
-p() { python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['ms_per_step'],2), {k: round(v,2) for k,v in d['kernel_ms_per_step'].items()})"; }
-for i in 1 2; do
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | p streams1
-FIREWORK_STREAMS=2 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | p streams2
-FIREWORK_STREAMS=4 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | p streams4
-done
+# batches in flight on separate HIP streams (FIREWORK_STREAMS=n), interleaved, cornell bench
+run() { python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-one-shot 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('kernel_ms_per_step',{}); print('$1', 'ms', round(d['ms_per_step'],2), 'Mrays/s', round(d['value']))"; }
+for rep in 1 2; do for n in 1 2 3 4; do FIREWORK_STREAMS=$n run streams$n; done; done
+python3 bench.py --gpus 2 --backend gloo --steps 5 --warmup 2 --no-cpu-baseline --no-one-shot 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('2 ranks gloo one gpu', round(d['ms_per_step'],2))"
+python3 bench.py --gpus 4 --backend gloo --steps 5 --warmup 2 --no-cpu-baseline --no-one-shot 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('4 ranks gloo one gpu', round(d['ms_per_step'],2))"
