@@ -6,9 +6,11 @@ committed under profiles/:
   <tag>_pmc.json          per-kernel HBM bytes from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes
   <tag>_sq.json           per-kernel SQ summary (wave-time split, VALU busy fraction, lane utilisation, instruction mix)
                           and the `bound` bench.py reports for the kernel:
-                            valu_issue  VALU pipes busy >= 60 % of the kernel's SIMD-cycles (at the 2.4 GHz peak clock, i.e. a lower bound)
                             hbm         HBM traffic >= 45 % of 8 TB/s
-                            latency     neither: waves parked in s_waitcnt
+                            valu_issue  the VALU pipes execute >= 50 % of what they can (one wave64 instruction per 2 cycles
+                                        per SIMD-32, at the 2.4 GHz peak clock: a lower bound), or the waves spend >= 25 % of
+                                        their time ready but not issued (SQ_WAIT_INST_ANY)
+                            latency     neither: waves parked in s_waitcnt behind dependent loads
 
 usage: scripts/summarize_prof.py <dir> <tag> "<workload string of bench.py's config.workload>"
 
@@ -65,7 +67,8 @@ def counters(src, sub):
 def main():
     src, tag, workload = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else None)
     os.makedirs(f"{ROOT}/profiles", exist_ok=True)
-    sha = kernel_source_sha()
+    sha_file = os.path.join(src, "source_sha.txt")         # written by tools/prof.sh on the GPU box: the build that was profiled
+    sha = open(sha_file).read().strip() if os.path.exists(sha_file) else kernel_source_sha()
     ks = newest(f"{src}/trace/**/*_kernel_stats.csv")
     if ks:
         shutil.copyfile(ks[0], f"{ROOT}/profiles/{tag}_kernel_stats.csv")
@@ -111,15 +114,16 @@ def main():
                "wave_time_split": {"waiting_s_waitcnt": round(v.get("SQ_WAIT_ANY", 0) * 4 / wc, 3) if wc else None,
                                    "issue_stall": round(v.get("SQ_WAIT_INST_ANY", 0) * 4 / wc, 3) if wc else None,
                                    "issuing": round(v.get("SQ_ACTIVE_INST_ANY", 0) * 4 / wc, 3) if wc else None},
-               "valu_busy_frac": round(v.get("SQ_ACTIVE_INST_VALU", 0) * 4 / simd_cycles, 3) if us else None,
+               "valu_pipe_util": round(v.get("SQ_INSTS_VALU", 0) * 2 / simd_cycles, 3) if us else None,      # 2 cycles per wave64 VALU instruction on a SIMD-32
+               "instr_per_simd_cycle": round(sum(v.get(n, 0) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS")) / simd_cycles, 3) if us else None,
                "valu_cycles_per_inst": round(v.get("SQ_ACTIVE_INST_VALU", 0) * 4 / v["SQ_INSTS_VALU"], 2) if v.get("SQ_INSTS_VALU") else None,
                "lane_utilisation": round(v.get("SQ_THREAD_CYCLES_VALU", 0) / (64 * v["SQ_INSTS_VALU"]), 3) if v.get("SQ_INSTS_VALU") else None,
                "insts": {n[9:]: v.get(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS") if n in v},
                "l2_hit_rate": round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 3) if v.get("TCC_HIT_sum") else None}
         hb = pmc["kernels"].get(k, {}).get("hbm_GBps")
         row["hbm_frac_of_8TBps"] = round(hb * 1e9 / HBM_PEAK, 3) if hb else None
-        vb = row["valu_busy_frac"] or 0.0
-        row["bound"] = "valu_issue" if vb >= 0.6 else ("hbm" if (row["hbm_frac_of_8TBps"] or 0) >= 0.45 else "latency")
+        vb, stall = row["valu_pipe_util"] or 0.0, row["wave_time_split"]["issue_stall"] or 0.0
+        row["bound"] = "hbm" if (row["hbm_frac_of_8TBps"] or 0) >= 0.45 else ("valu_issue" if (vb >= 0.5 or stall >= 0.25) else "latency")
         sq["kernels"][k] = row
     if sq["kernels"]:
         json.dump(sq, open(f"{ROOT}/profiles/{tag}_sq.json", "w"), indent=1)

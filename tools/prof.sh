@@ -5,6 +5,7 @@
 TAG=$1; shift
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O && cd /tmp
 B="--no-cpu-baseline --no-one-shot"
+(cd $R && python3 -c "import bench; print(bench.kernel_source_sha())") > $O/source_sha.txt     # the build these passes ran
 pass() { local name=$1; shift; local ctr="$1"; shift
   if [ -n "$ctr" ]; then timeout -k 10 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$name -- python3 $R/bench.py "$@" --steps 1 --warmup 0 $B > $O/$name.log 2>&1
   else timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -- python3 $R/bench.py "$@" --steps 3 --warmup 1 $B > $O/$name.log 2>&1; fi
