@@ -87,6 +87,8 @@ struct DScene {
     uint32_t has_medium;
     uint32_t has_mesh;
     uint32_t prim_bits;       // hit code = object << prim_bits | primitive
+    uint32_t n_hoisted;       // objects kept OUT of the walked TLAS because nearly every ray meets their box (part2's fog sphere
+    uint32_t hoisted[4];      // around the whole scene): tested for every ray, wave-uniformly, before the walk (hoisted_hits)
     DEnv env;
 };
 

@@ -772,6 +772,26 @@ struct BlockStream {
         }
     }
 };
+// The objects the host kept out of the walked TLAS (DScene.hoisted: boxes that cover most of the scene, met by nearly every
+// ray): tested here for one ray with wave-uniform object indices — scalar loads, no divergence between lanes — exactly as
+// their leaf would: the object's own box first (obj_cull = its leaf box in the walked tree), the gate box where it has one,
+// then the object with the caller's [TMIN, TMAX], ties by reference rank.  A walk that starts from this result culls
+// against its t like against any other hit.
+__device__ __forceinline__ void hoisted_hits(const DScene &sc, const Ray &r, V3 inv, const RngKey &key, int segment, uint32_t *blas_stack,
+                                             bool &have, float &best_t, uint32_t &best_obj, uint32_t &best_prim) {
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    for (uint32_t h = 0; h < sc.n_hoisted; h++) {
+        const uint32_t k = sc.hoisted[h];
+        if (!hit_aabb(sc.obj_cull[2 * (size_t)k], sc.obj_cull[2 * (size_t)k + 1], r.o, inv, TMIN, TMAX)) continue;
+        Obj o = load_obj(sc.obj, k);
+        if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)k], sc.obj_gate[2 * (size_t)k + 1], r.o, inv, TMIN, TMAX)) continue;
+        float t; uint32_t prim;
+        if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+            if (!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = k; best_prim = prim; }
+        }
+    }
+}
+
 // Closest hit of one ray: the linear scan of scene.rs:137-149 or the TLAS walk of bvh.rs:115-151.  With DEFER a
 // ray that reaches a mesh leaf of the TLAS reports (deferred, deferred_obj) instead of entering the BLAS.
 template <bool USE_BVH, bool DEFER>
@@ -826,6 +846,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
         LdsStack st{my_stack, 0};
         bool have = false;
         uint32_t cur = sc.tlas_root;
+        if (sc.n_hoisted) hoisted_hits(sc, r, inv, key, segment, blas_stack, have, best_t, best_obj, best_prim);
         // Rounds of (node steps, then object tests).  A lane walks pair nodes until it holds a leaf or is out of tree; the
         // WAVE stops walking once no more than a quarter of its busy lanes still walk, so that most lanes test their object now
         // instead of waiting for the stragglers, who go on in the next round (suzanne BLAS: 15.2 -> 12.2 ms with the same
@@ -987,6 +1008,11 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                         path_id = __float_as_uint(rs);
                         cur = sc.tlas_root; st.sp = 0;
                         have = false; best_t = TMAX; best_obj = MISS; best_prim = 0; deferred = false; deferred_obj = 0;
+                        if (!PARK && sc.n_hoisted) {      // objects are hoisted only in scenes without meshes
+                            RngKey hkey{0, 0, 0};
+                            if (sc.has_medium) hkey = key_of(f, path_id);
+                            hoisted_hits(sc, r, inv, hkey, segment, blas_stack, have, best_t, best_obj, best_prim);
+                        }
                     }
                     q_next += take;
                     if (q_next == cur_base + 64u && q_next < n) {      // cur is used up: nxt becomes cur, read 64 further ahead
@@ -1411,6 +1437,26 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
     uint32_t c_n = 0, c_pos = 0, c_base = 0, n_n = 0, n_base = 0;
     if (bs.next(c_base, c_n)) fetch(c_base, c_n, ca, cb, cs); else c_n = 0;
     if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
+    // When a block becomes current, all of its (up to 64) rays sit one per lane: the per-ray start-up work — the reciprocal
+    // direction (three divisions) and the hoisted objects (part2: the fog medium around everything, two sphere tests, a draw,
+    // a log10 per ray) — is done HERE with every lane busy, not at refill time by the few lanes that refill; the results ride
+    // in six more registers of the block and are handed out with the ray.
+    float h_t = TMAX, hix = 0.f, hiy = 0.f, hiz = 0.f; uint32_t h_obj = MISS, h_prim = 0;
+    auto prep_block = [&]() {
+        h_t = TMAX; h_obj = MISS; h_prim = 0;
+        if (lane < c_n) {
+            const Ray r = make_ray(ca, cb, f, segment);
+            const V3 iv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+            hix = iv.x; hiy = iv.y; hiz = iv.z;
+            if (sc.n_hoisted) {
+                RngKey hkey{0, 0, 0};
+                if (sc.has_medium) hkey = key_of(f, __float_as_uint(cs));
+                bool hv = false;
+                hoisted_hits(sc, r, iv, hkey, segment, nullptr, hv, h_t, h_obj, h_prim);
+            }
+        }
+    };
+    prep_block();
     const uint32_t IDLE = 0xffffffffu;
     uint32_t slot = IDLE, cur = REF_DONE, path_id = 0, best_obj = MISS, best_prim = 0;
     float best_t = TMAX; bool have = false;
@@ -1429,19 +1475,22 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
                 const float4 ra = make_float4(bp(ca.x), bp(ca.y), bp(ca.z), bp(ca.w));
                 const float2 rb = make_float2(bp(cb.x), bp(cb.y));
                 const float rs = sc.has_medium ? bp(cs) : 0.f;
+                const V3 rinv = mk(bp(hix), bp(hiy), bp(hiz));
+                const float rt = bp(h_t); const uint32_t robj = __float_as_uint(bp(__uint_as_float(h_obj))), rprim = __float_as_uint(bp(__uint_as_float(h_prim)));
                 if (slot == IDLE && rank < take) {
                     slot = c_base + src;
                     const Ray r = make_ray(ra, rb, f, segment);
                     wo = r.o; wd = r.d;
-                    inv = mk(fdiv(1.f, wd.x), fdiv(1.f, wd.y), fdiv(1.f, wd.z));
+                    inv = rinv;
                     path_id = __float_as_uint(rs);
                     cur = sc.tlas_root; st.sp = 0;
-                    have = false; best_t = TMAX; best_obj = MISS; best_prim = 0;
+                    have = robj != MISS; best_t = rt; best_obj = robj; best_prim = rprim;     // what the hoisted objects gave (prep_block)
                 }
                 c_pos += take;
                 if (c_pos == c_n) {
                     ca = na; cb = nb; cs = ns; c_n = n_n; c_base = n_base; c_pos = 0;
                     if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
+                    prep_block();
                 }
             }
         } else if (n_idle == 64u) break;

@@ -566,7 +566,37 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         float *c = &cull[(size_t)i * 8];
         c[0] = b.mn.x; c[1] = b.mn.y; c[2] = b.mn.z; c[4] = b.mx.x; c[5] = b.mx.y; c[6] = b.mx.z;
     }
-    if (use_sah()) { FlatBvh sah; sah_build(sah, build_boxes); tlas = std::move(sah); }
+    // Hoisting: an object whose box covers most of the scene (part2's r = 5000 fog medium) is met by nearly every ray, so in
+    // the tree its leaf is one more divergent leaf test per ray.  Scenes without meshes and too many objects for the scan keep
+    // such objects out of the WALKED tree; the kernels test them for every ray before the walk, with a wave-uniform index
+    // (hoisted_hits in fw_kernels.hip: same own-box test, same tie rule, so the same result as the leaf would give).
+    std::vector<uint32_t> hoisted;
+    if (use_sah() && desc->n_objects > 8 && fl.tri.empty() && getenv("FIREWORK_NO_HOIST") == nullptr) {
+        Box root = build_boxes[0];
+        for (const Box &b : build_boxes) root = box_union(root, b);
+        const float ra = box_area(root);
+        for (uint32_t i = 0; i < desc->n_objects && hoisted.size() < 4; i++)
+            if (box_area(build_boxes[i]) >= 0.5f * ra) hoisted.push_back(i);
+        if (desc->n_objects - hoisted.size() < 2) hoisted.clear();
+    }
+    if (use_sah()) {
+        FlatBvh sah;
+        if (hoisted.empty()) sah_build(sah, build_boxes);
+        else {
+            std::vector<Box> sub; std::vector<uint32_t> ids;
+            for (uint32_t i = 0; i < desc->n_objects; i++)
+                if (std::find(hoisted.begin(), hoisted.end(), i) == hoisted.end()) { sub.push_back(build_boxes[i]); ids.push_back(i); }
+            sah_build(sah, sub);
+            for (uint32_t i = 0; i < sah.count(); i++) {      // leaf items: positions in `sub` -> object ids
+                float *nd = &sah.nodes[(size_t)i * 8];
+                uint32_t A, B; std::memcpy(&A, nd + 3, 4); std::memcpy(&B, nd + 7, 4);
+                const uint32_t kind = A >> 30;
+                if (kind == fw::NODE_LEAF) { A = (kind << 30) | ids[A & fw::NODE_MASK]; std::memcpy(nd + 3, &A, 4); }
+                else if (kind == fw::NODE_DOUBLE) { A = (kind << 30) | ids[A & fw::NODE_MASK]; B = ids[B]; std::memcpy(nd + 3, &A, 4); std::memcpy(nd + 7, &B, 4); }
+            }
+        }
+        tlas = std::move(sah);
+    }
     PairBvh tlas_p;
     const uint32_t tlas_root = pair_convert(tlas, build_boxes, tlas_p);
 
@@ -699,6 +729,8 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.obj_cull = (const float4 *)(base + secs[12].off);
     d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
     d.prim_bits = prim_bits; d.tlas_root = tlas_root;
+    d.n_hoisted = (uint32_t)hoisted.size();
+    for (size_t i = 0; i < 4; i++) d.hoisted[i] = i < hoisted.size() ? hoisted[i] : 0u;
     d.env.kind = e.kind;
     d.env.color[0] = e.color.x; d.env.color[1] = e.color.y; d.env.color[2] = e.color.z;
     d.env.zenith[0] = e.zenith.x; d.env.zenith[1] = e.zenith.y; d.env.zenith[2] = e.zenith.z;
