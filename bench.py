@@ -339,7 +339,7 @@ def parity(args, tr, renderer, scene, frame_u8, cpu, cores):
     rms_lin = float(np.sqrt(np.mean((g.linear.astype(np.float64) - c.linear) ** 2)))
     return {"rms_gamma": rms, "rms_linear": rms_lin, "gate": 1e-3, "pass": bool(rms <= 1e-3),
             "u8_diffs": int((g.rgb8 != c.rgb8).sum()), "u8_values": int(c.rgb8.size),
-            "rays_equal": bool(g.stats["rays"] == c.stats["rays"]), "rays": int(g.stats["rays"]),
+            "rays_equal": bool(g.stats["rays"] == c.stats["rays"]), "rays_gpu": int(g.stats["rays"]), "rays_oracle": int(c.stats["rays"]),
             "timed_frame_equals_checked_frame": bool(np.array_equal(frame_u8[ids], g.rgb8)),
             "pixels": int(ids.shape[0]), "pixel_stride": stride, "spp": spp, "oracle_seconds": round(dt, 1),
             "what": f"{args.config} {w}x{h} @{spp}spp, every {stride}th pixel in x and y, GPU vs CPU oracle (FW_RNG_CTR, same seed)"}
