@@ -173,6 +173,8 @@ void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, 
 void launch_bounce(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, float4 *sample_rad, int segment,
                    bool use_bvh);
 void launch_queue_totals(const LaunchCfg &, uint32_t *totals, const uint32_t *ptotal);
+void launch_scatter_tiles(hipStream_t stream, const uint32_t *ids, uint32_t n, const uint8_t *in8, const float *ing, const float *inl,
+                          uint8_t *out8, float *outg, float *outl);
 void launch_tile_order(hipStream_t stream, uint32_t width, uint32_t height, uint32_t *ids);
 void launch_upload(hipStream_t stream, const void *pinned_src, void *dst, size_t bytes);
 void launch_count_deposits(const LaunchCfg &, const float4 *sample_rad, uint32_t n_slots, uint32_t *total);

@@ -2017,6 +2017,22 @@ void launch_upload(hipStream_t stream, const void *pinned_src, void *dst, size_t
                        (const uint4 *)pinned_src, (uint4 *)dst, n16);
 }
 
+// fw_render_scene_tiled's device-side gather: the tiles of every device, concatenated on the first one, go to their pixels
+__global__ __launch_bounds__(BLOCK) void k_scatter_tiles(const uint32_t *__restrict__ ids, uint32_t n, const uint8_t *__restrict__ in8,
+                                                         const float *__restrict__ ing, const float *__restrict__ inl,
+                                                         uint8_t *__restrict__ out8, float *__restrict__ outg, float *__restrict__ outl) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const size_t s = 3 * (size_t)i, d = 3 * (size_t)ids[i];
+        if (in8) { out8[d] = in8[s]; out8[d + 1] = in8[s + 1]; out8[d + 2] = in8[s + 2]; }
+        if (ing) { outg[d] = ing[s]; outg[d + 1] = ing[s + 1]; outg[d + 2] = ing[s + 2]; }
+        if (inl) { outl[d] = inl[s]; outl[d + 1] = inl[s + 1]; outl[d + 2] = inl[s + 2]; }
+    }
+}
+void launch_scatter_tiles(hipStream_t stream, const uint32_t *ids, uint32_t n, const uint8_t *in8, const float *ing, const float *inl,
+                          uint8_t *out8, float *outg, float *outl) {
+    hipLaunchKernelGGL(k_scatter_tiles, dim3(std::min<uint32_t>((n + BLOCK - 1) / BLOCK, 4096u)), dim3(BLOCK), 0, stream, ids, n, in8, ing, inl, out8, outg, outl);
+}
+
 __device__ __forceinline__ uint8_t sat_u8(float f) { if (!(f > 0.f)) return 0; if (f >= 255.f) return 255; return (uint8_t)f; }
 
 __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame f, const float4 *__restrict__ accum, uint32_t total_spp, float gamma,

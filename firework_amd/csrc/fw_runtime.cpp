@@ -1161,8 +1161,30 @@ int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *par
             const uint32_t owner = (t % tx + t / tx) % (uint32_t)N, y0 = (t / tx) * TILE, x0 = (t % tx) * TILE;
             for (uint32_t y = y0; y < std::min(y0 + TILE, H); y++) for (uint32_t x = x0; x < std::min(x0 + TILE, W); x++) ids[owner].push_back(y * W + x);
         }
-        struct Part { int rc = FW_OK; std::string err; fw_stats st{}; std::vector<uint8_t> c8; std::vector<float> cg, cl; double ms_scene = 0; };
+        // Device-side gather (round 2): every device renders its tiles into its OWN memory, copies them peer-to-peer
+        // (hipMemcpyPeer: over xGMI where the devices are linked) into one buffer on the first device, which scatters them to
+        // their pixels and sends the finished frames to the host once — instead of one D2H per device and a host-side scatter.
+        struct Part { int rc = FW_OK; std::string err; fw_stats st{}; double ms_scene = 0; };
         std::vector<Part> parts(N);
+        std::vector<size_t> first(N + 1, 0);                       // part r holds the concatenated entries [first[r], first[r+1])
+        for (int r = 0; r < N; r++) first[r + 1] = first[r] + ids[r].size();
+        const size_t n_total = first[N];
+        const int dev0 = devices[0];
+        HIPCHK(hipSetDevice(dev0));
+        // on the first device: [ids | gathered rgb8 | gamma | linear | frame rgb8 | gamma | linear], 256-byte aligned sections
+        auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        const size_t b8 = rgb8 ? n_total * 3 : 0, bg = gamma_rgb ? n_total * 12 : 0, bl = linear_rgb ? n_total * 12 : 0;
+        const size_t o_ids = 0, o_g8 = al(n_total * 4), o_gg = o_g8 + al(b8), o_gl = o_gg + al(bg), o_f8 = o_gl + al(bl), o_fg = o_f8 + al(b8),
+                     o_fl = o_fg + al(bg), dev_bytes = o_fl + al(bl) + 256;
+        DevBuf gather;
+        int grc = gather.alloc(dev_bytes);
+        if (grc) return grc;
+        uint8_t *gb = (uint8_t *)gather.p;
+        {
+            std::vector<uint32_t> all_ids; all_ids.reserve(n_total);
+            for (int r = 0; r < N; r++) all_ids.insert(all_ids.end(), ids[r].begin(), ids[r].end());
+            if (hipMemcpy(gb + o_ids, all_ids.data(), n_total * 4, hipMemcpyHostToDevice) != hipSuccess) { gather.release(); return fail(FW_ERR_HIP, "tile id upload failed"); }
+        }
         std::vector<std::thread> threads;
         for (int r = 0; r < N; r++) threads.emplace_back([&, r] {
             Part &pt = parts[r];
@@ -1174,27 +1196,41 @@ int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *par
                 pt.rc = fw_scene_create(desc, devices[r], &sc);
                 if (pt.rc) { pt.err = g_last_error; return; }
                 pt.ms_scene = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-                fw_render_params p = *params;
-                p.pixel_ids = ids[r].data(); p.n_pixels = (uint32_t)n; p.stream = nullptr;
-                if (rgb8) pt.c8.resize(n * 3);
-                if (gamma_rgb) pt.cg.resize(n * 3);
-                if (linear_rgb) pt.cl.resize(n * 3);
-                pt.rc = fw_render(sc, &p, rgb8 ? pt.c8.data() : nullptr, gamma_rgb ? pt.cg.data() : nullptr, linear_rgb ? pt.cl.data() : nullptr, &pt.st);
-                if (pt.rc) pt.err = g_last_error;
+                DevBuf part;                                            // this device's tiles, in its own HBM
+                const size_t p8 = rgb8 ? n * 3 : 0, pg = gamma_rgb ? n * 12 : 0, pl = linear_rgb ? n * 12 : 0;
+                const size_t q8 = 0, qg = al(p8), ql = qg + al(pg);
+                (void)hipSetDevice(devices[r]);
+                pt.rc = part.alloc(ql + al(pl) + 256);
+                if (!pt.rc) {
+                    uint8_t *pb = (uint8_t *)part.p;
+                    fw_render_params p = *params;
+                    p.pixel_ids = ids[r].data(); p.n_pixels = (uint32_t)n; p.stream = nullptr; p.outputs_on_device = 1;
+                    pt.rc = fw_render(sc, &p, rgb8 ? pb + q8 : nullptr, gamma_rgb ? (float *)(pb + qg) : nullptr, linear_rgb ? (float *)(pb + ql) : nullptr, &pt.st);
+                    if (pt.rc) pt.err = g_last_error;
+                    auto peer = [&](size_t dst_off, size_t src_off, size_t bytes) {
+                        if (!pt.rc && bytes && hipMemcpyPeer(gb + dst_off, dev0, pb + src_off, devices[r], bytes) != hipSuccess) { pt.rc = FW_ERR_HIP; pt.err = "hipMemcpyPeer of a device's tiles failed"; }
+                    };
+                    peer(o_g8 + first[r] * 3, q8, p8); peer(o_gg + first[r] * 12, qg, pg); peer(o_gl + first[r] * 12, ql, pl);
+                } else pt.err = g_last_error;
+                part.release();
                 fw_scene_destroy(sc);
             } catch (...) { pt.rc = FW_ERR_OOM; pt.err = "host allocation failed in a tile worker"; }
         });
         for (auto &t : threads) t.join();
-        for (int r = 0; r < N; r++) if (parts[r].rc) return fail(parts[r].rc, parts[r].err);
+        for (int r = 0; r < N; r++) if (parts[r].rc) { (void)hipSetDevice(dev0); gather.release(); return fail(parts[r].rc, parts[r].err); }
+        // the one scatter and the one device -> host transfer
+        (void)hipSetDevice(dev0);
+        fw::launch_scatter_tiles(nullptr, (const uint32_t *)(gb + o_ids), (uint32_t)n_total, rgb8 ? gb + o_g8 : nullptr, gamma_rgb ? (const float *)(gb + o_gg) : nullptr,
+                                 linear_rgb ? (const float *)(gb + o_gl) : nullptr, gb + o_f8, (float *)(gb + o_fg), (float *)(gb + o_fl));
+        hipError_t ce = hipSuccess;
+        if (rgb8 && ce == hipSuccess) ce = hipMemcpy(rgb8, gb + o_f8, b8, hipMemcpyDeviceToHost);
+        if (gamma_rgb && ce == hipSuccess) ce = hipMemcpy(gamma_rgb, gb + o_fg, bg, hipMemcpyDeviceToHost);
+        if (linear_rgb && ce == hipSuccess) ce = hipMemcpy(linear_rgb, gb + o_fl, bl, hipMemcpyDeviceToHost);
+        gather.release();
+        if (ce != hipSuccess) return fail(FW_ERR_HIP, hipGetErrorString(ce));
         if (stats) std::memset(stats, 0, sizeof *stats);
         for (int r = 0; r < N; r++) {
             const Part &pt = parts[r];
-            for (size_t i = 0; i < ids[r].size(); i++) {     // the one "gather": <= W*H*27 bytes over PCIe, already in host memory here
-                const size_t d = (size_t)ids[r][i] * 3;
-                if (rgb8) std::memcpy(rgb8 + d, &pt.c8[i * 3], 3);
-                if (gamma_rgb) std::memcpy(gamma_rgb + d, &pt.cg[i * 3], 12);
-                if (linear_rgb) std::memcpy(linear_rgb + d, &pt.cl[i * 3], 12);
-            }
             if (stats && !ids[r].empty()) {
                 stats->samples += pt.st.samples; stats->rays += pt.st.rays; stats->algorithmic_bytes += pt.st.algorithmic_bytes;
                 stats->bytes_raygen += pt.st.bytes_raygen; stats->bytes_extend += pt.st.bytes_extend; stats->bytes_shade += pt.st.bytes_shade;

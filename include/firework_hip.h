@@ -254,7 +254,9 @@ int fw_render(fw_scene *scene, const fw_render_params *params,
 /* One-shot render of a whole frame on SEVERAL GPUs from ONE process (what a single Rust binary calls; the Python hosts of
    this repo use one process per GPU and an RCCL gather instead): the frame is cut into 16x16 tiles dealt diagonally over the
    devices, one host thread per device creates the scene there and renders its pixels — with the keys a single GPU would
-   use, so the image is bit-identical for any device list — and the tiles are scattered into the caller's host buffers.
+   use, so the image is bit-identical for any device list — copies its finished tiles peer-to-peer (hipMemcpyPeer: xGMI where
+   the devices are linked) to the first listed device, which scatters them to their pixels and sends the frames to the
+   caller's host buffers in one transfer.
    `devices` may name a device more than once (its calls are serialised).  render.rs:127-131 shards pixels over rayon workers
    the same way.  stats: counters summed, times = the slowest device. */
 int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *params, const int *devices, int n_devices,
