@@ -177,7 +177,7 @@ void launch_scatter_tiles(hipStream_t stream, const uint32_t *ids, uint32_t n, c
                           uint8_t *out8, float *outg, float *outl);
 void launch_tile_order(hipStream_t stream, uint32_t width, uint32_t height, uint32_t *ids);
 void launch_upload(hipStream_t stream, const void *pinned_src, void *dst, size_t bytes);
-void launch_count_deposits(const LaunchCfg &, const float4 *sample_rad, uint32_t n_slots, uint32_t *total);
+void launch_count_deposits(const LaunchCfg &, const float4 *sample_rad, uint32_t *total);
 void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out);
 void launch_accumulate(const LaunchCfg &, const DFrame &, const float4 *sample_rad, float4 *accum);
 void launch_resolve(const LaunchCfg &, const DFrame &, const float4 *accum, uint32_t total_spp, float gamma,

@@ -24,6 +24,7 @@
 // association as the reference's expressions, so hit/miss decisions follow the CPU oracle bit for
 // bit; only libm-class functions (sin, atan2, asin, log10, pow) differ by ulps.
 #include "fw_device.h"
+#include <atomic>
 
 namespace fw {
 
@@ -1935,10 +1936,12 @@ __global__ __launch_bounds__(BLOCK) void k_queue_totals(DQueue q, uint32_t *tota
 }
 // FW_FLAG_COUNT_DEPOSITS: how many radiance records k_shade wrote in this batch.  Over a black environment k_raygen zeroes
 // every record and k_shade elides the zeros, so the records that are not all-zero are exactly the ones written.
-__global__ __launch_bounds__(BLOCK) void k_count_deposits(const float4 *__restrict__ sample_rad, uint32_t n_slots, uint32_t *total) {
+__global__ __launch_bounds__(BLOCK) void k_count_deposits(const float4 *__restrict__ sample_rad, DQueue q, uint32_t *total) {
     __shared__ uint32_t part[BLOCK];
+    const uint32_t n_slots = q.n_waves * q.cap, shift = q.cpw_shift + 6u;
     uint32_t acc = 0;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_slots; i += gridDim.x * BLOCK) {
+        if ((i & (q.cap - 1u)) >= q.wcount[i >> shift]) continue;      // only the slots k_raygen filled in this batch (segment-0 queue lengths)
         const float4 v = sample_rad[i];
         acc += (v.x != 0.f || v.y != 0.f || v.z != 0.f) ? 1u : 0u;
     }
@@ -1947,7 +1950,6 @@ __global__ __launch_bounds__(BLOCK) void k_count_deposits(const float4 *__restri
     for (uint32_t s2 = BLOCK / 2; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2]; __syncthreads(); }
     if (threadIdx.x == 0 && part[0]) atomicAdd(total, part[0]);
 }
-
 // ------------------------------------------------------------------------------------------------
 // K8  accumulate (sample order, deterministic) and resolve
 // ------------------------------------------------------------------------------------------------
@@ -2089,6 +2091,14 @@ static dim3 wave_grid(const LaunchCfg &c) { return dim3((c.q.n_waves + WB / 64 -
 void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPaths out, float4 *sample_rad, uint32_t n_paths) {
     hipLaunchKernelGGL(k_raygen, wave_grid(c), dim3(WB), 0, c.stream, cam, f, out, sample_rad, c.q, n_paths);
 }
+// More than 64 KB of dynamic LDS has to be allowed per kernel AND per device (a process may drive several: fw_render_scene_tiled):
+// true the first time kernel group `which` is about to be launched on the current device.
+static bool lds_attr_needed(int which) {
+    static std::atomic<unsigned char> done[2][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    return done[which][dev].exchange(1) == 0;
+}
 void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float2 *hits, int segment, bool use_bvh, DPark park) {
     int tl = use_bvh ? c.tlas_depth + 1 : 0;
     int levels = tl + c.blas_depth + 1;
@@ -2103,11 +2113,9 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
         const uint32_t bl = (uint32_t)c.blas_depth + 1u;
         const size_t lds_blas = (size_t)c.blas_pair_nodes * 64 + (size_t)LDS_WAVES * bl * 64 * 2 + 16, lds_tris = (size_t)c.n_tris * 48;
         if (c.lds_trees && c.blas_pair_nodes > 0 && c.blas_pair_nodes < 32768u && c.max_tris < 32768u && lds_blas <= LDS_TREE_LIMIT) {
-            static bool attr_set = false;
-            if (!attr_set) {
+            if (lds_attr_needed(0)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
-                attr_set = true;
             }
             const dim3 lg(std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES));
             if (lds_blas + lds_tris <= LDS_TREE_LIMIT && !c.no_lds_tris)      // the triangles too, when they fit as well
@@ -2121,8 +2129,7 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
         // scenes without meshes: the whole TLAS in LDS when it fits next to sixteen 16-bit stacks
         const size_t lds_tlas = (size_t)c.tlas_pair_nodes * 64 + (size_t)LDS_WAVES * (uint32_t)tl * 64 * 2 + 16;
         if (c.lds_trees && !c.has_mesh && sc.n_objects > TLAS_SCAN_MAX && c.tlas_pair_nodes < 32768u && sc.n_objects < 32768u && lds_tlas <= LDS_TREE_LIMIT) {
-            static bool attr_set = false;
-            if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT); attr_set = true; }
+            if (lds_attr_needed(1)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
             hipLaunchKernelGGL(k_extend_tlas_lds, dim3(std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES)), dim3(LDS_WAVES * 64), lds_tlas, c.stream,
                                sc, f, in, hits, c.q, segment, c.tlas_pair_nodes, (uint32_t)tl);
         }
@@ -2165,8 +2172,8 @@ extern "C" int fw_debug_trav_stats(unsigned long long out[8]) {   // debug build
 void launch_queue_totals(const LaunchCfg &c, uint32_t *totals, const uint32_t *ptotal) {
     hipLaunchKernelGGL(k_queue_totals, dim3(32, MAX_SEGMENTS + 1), dim3(BLOCK), 0, c.stream, c.q, totals, ptotal);   // totals are zeroed per frame
 }
-void launch_count_deposits(const LaunchCfg &c, const float4 *sample_rad, uint32_t n_slots, uint32_t *total) {
-    hipLaunchKernelGGL(k_count_deposits, dim3(2048), dim3(BLOCK), 0, c.stream, sample_rad, n_slots, total);
+void launch_count_deposits(const LaunchCfg &c, const float4 *sample_rad, uint32_t *total) {
+    hipLaunchKernelGGL(k_count_deposits, dim3(2048), dim3(BLOCK), 0, c.stream, sample_rad, c.q, total);
 }
 void launch_accumulate(const LaunchCfg &c, const DFrame &f, const float4 *sample_rad, float4 *accum) {
     uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)f.n_pixels + WB - 1) / WB, 65536));

@@ -964,7 +964,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             cur ^= 1;
         }
         timed(3, [&] { fw::launch_queue_totals(cfg, totals, park.ptotal); });
-        if (count_deposits) fw::launch_count_deposits(cfg, srad, cap, totals + 12);   // not a kernel class: after the last timed event of its neighbours
+        if (count_deposits) fw::launch_count_deposits(cfg, srad, totals + 12);   // not a kernel class: after the last timed event of its neighbours
         // `total_color += color(..)` in sample order (render.rs:181): batch b is accumulated after batch b-1, whichever
         // lanes they ran on, so the image does not depend on the number of lanes or batches
         if (n_lanes > 1 && b > 0) HIPCHK(hipStreamWaitEvent(ls, ws->events[3 + b - 1], 0));

@@ -171,3 +171,33 @@ def test_bench_line_carries_roofline_parity_and_one_shot():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     lay, sur = d["roofline_frame"]["layout"], d["roofline_frame"]["survey"]
     assert 0 < lay["bytes"] < sur["bytes"]
+
+
+def test_stats_carry_the_layouts_own_bytes_and_the_deposits_really_written():
+    """fw_stats (ABI v4): bytes per kernel class follow from the per-depth ray counts by the layout's record sizes
+    (fw_device.h B_*), and FW_FLAG_COUNT_DEPOSITS counts the radiance records k_shade wrote — fewer than the samples over a
+    black environment, where zeros are elided — independently of what an earlier, bigger render left in the workspace."""
+    s, r = scenes.config("C2_cornell_box", 96, 96, 32)
+    big = scenes.config("C2_cornell_box", 160, 160, 16)
+    big[1].render_full(big[0])                                        # leaves non-zero records beyond this frame's slots
+    a = r.count_deposits(True).render_full(s).stats
+    R, S = a["rays_per_depth"], a["samples"]
+    assert 0 < a["deposits"] < S                                      # most cornell paths end black
+    later, ray0 = sum(R[1:]), 16                                      # pinhole camera: segment-0 rays are 16 B
+    rd_ray = R[0] * ray0 + later * 24
+    assert a["bytes_extend"] == rd_ray + 8 * a["rays"]
+    assert a["bytes_shade"] == rd_ray + later * 16 + 8 * a["rays"] + later * 40 + a["deposits"] * 16
+    assert a["bytes_raygen"] == S * ray0 + S * 16 + S * 4             # rays + zeroed deposits + the tile-order ids
+    b = r.render_full(s).stats                                        # again, same workspace: same count
+    assert b["deposits"] == a["deposits"]
+    c = r.count_deposits(False).render_full(s).stats
+    assert c["deposits"] == S and c["bytes_shade"] > a["bytes_shade"]  # without the count every terminated path is assumed to write
+    # a sky environment: nothing is elided
+    s2, r2 = scenes.config("C4b_volume_test", 64, 64, 8)
+    d = r2.count_deposits(True).render_full(s2).stats
+    assert d["deposits"] == d["samples"]
+    # parked rays are counted where a mesh is walked by k_blas
+    s3, r3 = scenes.config("C3_suzanne", 96, 54, 8)
+    e = r3.render_full(s3).stats
+    assert 0 < e["parked_rays"] < e["rays"] and e["bytes_extend"] > 32 * e["rays"] - 8 * e["samples"]
+    assert e["ms_wall"] >= e["ms_render"] > 0 and e["ms_d2h"] >= 0
