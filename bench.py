@@ -228,10 +228,11 @@ def roofline_objects(acc, args, tr, renderer):
     sha = kernel_source_sha()
     traffic = traffic_src = frac_traffic = None
     other_bound = other_src = None
+    workload = f"{args.config} {renderer.settings['width']}x{renderer.settings['height']} @{renderer.settings['samples']}spp"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
             d = json.load(open(path))
-            if d.get("source_sha") != sha or d.get("workload") != f"{args.config} {renderer.settings['width']}x{renderer.settings['height']} @{renderer.settings['samples']}spp":
+            if d.get("source_sha") != sha or d.get("workload") != workload:
                 continue
             k = [k for k in d["kernels"] if "k_shade" in k][0]
             traffic, traffic_src = d["kernels"][k]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
@@ -241,9 +242,9 @@ def roofline_objects(acc, args, tr, renderer):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq.json")), reverse=True):
         try:
             d = json.load(open(path))
-            if d.get("source_sha") != sha:
+            if d.get("source_sha") != sha or d.get("workload") != workload:
                 continue
-            k = [k for k in d["kernels"] if "k_extend" in k][0]
+            k = max((k for k in d["kernels"] if "k_extend" in k or "k_blas" in k), key=lambda k: d["kernels"][k]["us_total"])   # the longest of the extend-class kernels
             other_bound, other_src = d["kernels"][k]["bound"], os.path.relpath(path, ROOT)
             break
         except Exception:
