@@ -209,6 +209,8 @@ def main():
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     tr.close()
     if use_dist:
+        if world > 1:
+            dist.barrier()          # rank 0 finishes its extra (untimed) work before any rank tears the group down
         dist.destroy_process_group()
 
 
