@@ -140,6 +140,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_dist:      # communicator set-up (seconds for RCCL) must not land in a timed step when --warmup is 0
+        dist.barrier()
+        tr.tg.assemble()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         tr.render_frame()
     barrier()
