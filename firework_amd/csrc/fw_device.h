@@ -109,7 +109,8 @@ struct DFrame {
     float inv_width;              // 1.0f / width
     float inv_n_pixels;           // 1.0f / n_pixels (path_id -> sample index without an integer division)
     uint32_t q_n_waves, q_shift;  // the batch's queue geometry (DQueue n_waves, cpw_shift): home slot <-> linear path id
-    uint32_t skip_zero_deposits;  // black environment: k_raygen zeroes the deposits, k_shade writes only non-zero radiance
+    uint32_t skip_zero_deposits;  // black environment: k_shade writes only non-zero radiance records and sets their bit in dep_bits
+    uint32_t *dep_bits;           // one bit per path slot (zeroed per batch): k_accumulate reads a record only where it is set
     uint32_t pinhole0;            // aperture 0: every camera ray starts at cam_pos, segment-0 rays are stored as 16 B (direction only)
     float cam_pos[3];
 };
@@ -177,7 +178,7 @@ void launch_scatter_tiles(hipStream_t stream, const uint32_t *ids, uint32_t n, c
                           uint8_t *out8, float *outg, float *outl);
 void launch_tile_order(hipStream_t stream, uint32_t width, uint32_t height, uint32_t *ids);
 void launch_upload(hipStream_t stream, const void *pinned_src, void *dst, size_t bytes);
-void launch_count_deposits(const LaunchCfg &, const float4 *sample_rad, uint32_t *total);
+void launch_count_deposits(const LaunchCfg &, const uint32_t *dep_bits, uint32_t *total);
 void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out);
 void launch_accumulate(const LaunchCfg &, const DFrame &, const float4 *sample_rad, float4 *accum);
 void launch_resolve(const LaunchCfg &, const DFrame &, const float4 *accum, uint32_t total_spp, float gamma,

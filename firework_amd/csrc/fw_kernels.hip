@@ -274,7 +274,6 @@ __global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out
                 qst(&out.ray_a[slot], make_float4(o.x, o.y, o.z, d.x));
                 qst(&out.ray_b[slot], make_float2(d.y, d.z));
             }
-            if (f.skip_zero_deposits) sample_rad[slot] = make_float4(0.f, 0.f, 0.f, 0.f);   // dense here, so k_shade can skip the scattered zeros
         }
         produced += min(64u, n_paths - id0);
     }
@@ -1804,6 +1803,7 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
     if (!alive && !(f.skip_zero_deposits && rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
         if (FW_NT_RAD) st_nt(&sample_rad[path_id], make_float4(rad.x, rad.y, rad.z, 0.f));
         else sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, 0.f);
+        if (f.skip_zero_deposits) atomicOr(&f.dep_bits[path_id >> 5], 1u << (path_id & 31u));   // "this slot holds a record" (3.6 % of cornell's paths)
     }
     return alive;
 }
@@ -1934,17 +1934,11 @@ __global__ __launch_bounds__(BLOCK) void k_queue_totals(DQueue q, uint32_t *tota
     for (uint32_t s2 = BLOCK / 2; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2]; __syncthreads(); }
     if (threadIdx.x == 0 && part[0]) atomicAdd(&totals[seg], part[0]);
 }
-// FW_FLAG_COUNT_DEPOSITS: how many radiance records k_shade wrote in this batch.  Over a black environment k_raygen zeroes
-// every record and k_shade elides the zeros, so the records that are not all-zero are exactly the ones written.
-__global__ __launch_bounds__(BLOCK) void k_count_deposits(const float4 *__restrict__ sample_rad, DQueue q, uint32_t *total) {
+// FW_FLAG_COUNT_DEPOSITS: how many radiance records k_shade wrote in this batch = the bits set in dep_bits.
+__global__ __launch_bounds__(BLOCK) void k_count_deposits(const uint32_t *__restrict__ dep_bits, uint32_t n_words, uint32_t *total) {
     __shared__ uint32_t part[BLOCK];
-    const uint32_t n_slots = q.n_waves * q.cap, shift = q.cpw_shift + 6u;
     uint32_t acc = 0;
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_slots; i += gridDim.x * BLOCK) {
-        if ((i & (q.cap - 1u)) >= q.wcount[i >> shift]) continue;      // only the slots k_raygen filled in this batch (segment-0 queue lengths)
-        const float4 v = sample_rad[i];
-        acc += (v.x != 0.f || v.y != 0.f || v.z != 0.f) ? 1u : 0u;
-    }
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n_words; i += gridDim.x * BLOCK) acc += (uint32_t)__popc(dep_bits[i]);
     part[threadIdx.x] = acc;
     __syncthreads();
     for (uint32_t s2 = BLOCK / 2; s2 > 0; s2 >>= 1) { if (threadIdx.x < s2) part[threadIdx.x] += part[threadIdx.x + s2]; __syncthreads(); }
@@ -1972,6 +1966,23 @@ __global__ __launch_bounds__(WB) void k_accumulate(DFrame f, const float4 *__res
             return home;
         };
         uint32_t s = 0;
+        if (f.skip_zero_deposits) {
+            // black environment: only the slots whose bit is set hold a record (k_shade), all others contribute an exact +0:
+            // 1 bit instead of 16 bytes per sample is read, and nobody had to write the zeros
+            for (; s + 16u <= f.spp_batch; s += 16u) {
+                uint32_t h[16], bw[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { h[k] = home_then_advance(); bw[k] = f.dep_bits[h[k] >> 5]; }
+#pragma unroll
+                for (int k = 0; k < 16; k++) if ((bw[k] >> (h[k] & 31u)) & 1u) { const float4 v = sample_rad[h[k]]; a.x += v.x; a.y += v.y; a.z += v.z; }
+            }
+            for (; s < f.spp_batch; s++) {
+                const uint32_t h = home_then_advance();
+                if ((f.dep_bits[h >> 5] >> (h & 31u)) & 1u) { const float4 v = sample_rad[h]; a.x += v.x; a.y += v.y; a.z += v.z; }
+            }
+            accum[p] = a;
+            continue;
+        }
         for (; s + 16u <= f.spp_batch; s += 16u) {
             float4 v[16];
 #pragma unroll
@@ -2172,8 +2183,8 @@ extern "C" int fw_debug_trav_stats(unsigned long long out[8]) {   // debug build
 void launch_queue_totals(const LaunchCfg &c, uint32_t *totals, const uint32_t *ptotal) {
     hipLaunchKernelGGL(k_queue_totals, dim3(32, MAX_SEGMENTS + 1), dim3(BLOCK), 0, c.stream, c.q, totals, ptotal);   // totals are zeroed per frame
 }
-void launch_count_deposits(const LaunchCfg &c, const float4 *sample_rad, uint32_t *total) {
-    hipLaunchKernelGGL(k_count_deposits, dim3(2048), dim3(BLOCK), 0, c.stream, sample_rad, c.q, total);
+void launch_count_deposits(const LaunchCfg &c, const uint32_t *dep_bits, uint32_t *total) {
+    hipLaunchKernelGGL(k_count_deposits, dim3(1024), dim3(BLOCK), 0, c.stream, dep_bits, (c.q.n_waves * c.q.cap + 31u) / 32u, total);
 }
 void launch_accumulate(const LaunchCfg &c, const DFrame &f, const float4 *sample_rad, float4 *accum) {
     uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)f.n_pixels + WB - 1) / WB, 65536));

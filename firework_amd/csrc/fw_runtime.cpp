@@ -277,7 +277,7 @@ struct DevBuf {
 // depend on n (batches are accumulated in order).  Default 1: the measured gain is ~3 %.
 struct Workspace {
     static constexpr int MAX_LANES = 4;
-    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, wcount, park_a, park_b, park_m, pcount;
+    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, wcount, park_a, park_b, park_m, pcount, dep_bits;
                   hipStream_t stream = nullptr; std::vector<hipEvent_t> events; };
     std::mutex mu;                        // one fw_render at a time per device
     Lane lanes[MAX_LANES];
@@ -297,7 +297,7 @@ struct Workspace {
         tile_ids.release(); tile_w = tile_h = 0;
         for (DevBuf *b : {&accum, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear, &scene_cache}) b->release();
         for (Lane &l : lanes) {
-            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount, &l.park_a, &l.park_b, &l.park_m, &l.pcount}) b->release();
+            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount, &l.park_a, &l.park_b, &l.park_m, &l.pcount, &l.dep_bits}) b->release();
             for (hipEvent_t e : l.events) (void)hipEventDestroy(e);
             l.events.clear();
             if (l.stream) (void)hipStreamDestroy(l.stream);
@@ -845,6 +845,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         for (int k = 0; k < 2; k++) { need(L.ray_a[k], (size_t)cap * 16); need(L.ray_b[k], (size_t)cap * 8); need(L.state[k], (size_t)cap * 16); }
         need(L.hits, (size_t)cap * 8);
         need(L.sample_rad, (size_t)cap * 16);                 // indexed by home slot
+        need(L.dep_bits, ((size_t)cap + 31) / 32 * 4);        // one bit per slot: "a radiance record was written here" (black environments)
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
         if (park_meshes) {     // rays handed from k_extend_tlas_park to k_blas: 40 B per slot
             const size_t pcap = (size_t)(q.cap + 64u) * q.n_waves;     // park regions: q.cap + 64 entries per queue (DPark.stride)
@@ -943,6 +944,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         };
         if (timing && ev_next[l] == 0) (void)hipEventRecord(L.events[0], ls);
         fr.sample0 = first_sample + b * spp_b;
+        fr.dep_bits = (uint32_t *)L.dep_bits.p;
+        if (fr.skip_zero_deposits) HIPCHK(hipMemsetAsync(fr.dep_bits, 0, ((size_t)cap + 31) / 32 * 4, ls));
         fr.spp_batch = std::min(spp_b, p->samples - b * spp_b);
         uint32_t n_paths = n_pix * fr.spp_batch;
         uint32_t *totals = (uint32_t *)ws->totals.p + (size_t)b * fw::COUNT_STRIDE;
@@ -964,7 +967,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             cur ^= 1;
         }
         timed(3, [&] { fw::launch_queue_totals(cfg, totals, park.ptotal); });
-        if (count_deposits) fw::launch_count_deposits(cfg, srad, totals + 12);   // not a kernel class: after the last timed event of its neighbours
+        if (count_deposits) fw::launch_count_deposits(cfg, fr.dep_bits, totals + 12);   // not a kernel class: after the last timed event of its neighbours
         // `total_color += color(..)` in sample order (render.rs:181): batch b is accumulated after batch b-1, whichever
         // lanes they ran on, so the image does not depend on the number of lanes or batches
         if (n_lanes > 1 && b > 0) HIPCHK(hipStreamWaitEvent(ls, ws->events[3 + b - 1], 0));
@@ -1033,7 +1036,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             const uint64_t S = stats->samples, ray0 = fr.pinhole0 ? fw::B_RAY_PINHOLE0 : fw::B_RAY;
             uint64_t rd_ray = R[0] * ray0, later = 0, survivors = 0;
             for (int s = 1; s < fw::MAX_SEGMENTS; s++) { rd_ray += R[s] * fw::B_RAY; later += R[s]; survivors += R[s]; }
-            stats->bytes_raygen = S * ray0 + (fr.skip_zero_deposits ? S * fw::B_DEPOSIT : 0) + (fr.pixel_ids ? S * 4 : 0);
+            stats->bytes_raygen = S * ray0 + (fr.pixel_ids ? S * 4 : 0);
             const uint64_t medium = sc->d.has_medium ? later * 4 : 0;       // the path's home slot (RNG key of the medium's draw)
             const uint64_t shade_in = rd_ray + later * fw::B_STATE, shade_out = survivors * (fw::B_RAY + fw::B_STATE) + stats->deposits * fw::B_DEPOSIT;
             if (fused) { stats->bytes_extend = 0; stats->bytes_shade = shade_in + shade_out; }
@@ -1041,7 +1044,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
                 stats->bytes_extend = rd_ray + medium + stats->rays * fw::B_HIT + stats->parked_rays * 2 * fw::B_PARK;
                 stats->bytes_shade = shade_in + stats->rays * fw::B_HIT + shade_out;
             }
-            stats->bytes_accumulate = S * fw::B_DEPOSIT + (uint64_t)n_batches * n_pix * 2 * fw::B_ACCUM;
+            stats->bytes_accumulate = (fr.skip_zero_deposits ? stats->deposits * fw::B_DEPOSIT + S / 8 : S * fw::B_DEPOSIT) + (uint64_t)n_batches * n_pix * 2 * fw::B_ACCUM;
         }
         stats->ms_wall = std::chrono::duration<double, std::milli>(wall1 - wall0).count();
         float ms_copy = 0.f;

@@ -187,7 +187,8 @@ def test_stats_carry_the_layouts_own_bytes_and_the_deposits_really_written():
     rd_ray = R[0] * ray0 + later * 24
     assert a["bytes_extend"] == rd_ray + 8 * a["rays"]
     assert a["bytes_shade"] == rd_ray + later * 16 + 8 * a["rays"] + later * 40 + a["deposits"] * 16
-    assert a["bytes_raygen"] == S * ray0 + S * 16 + S * 4             # rays + zeroed deposits + the tile-order ids
+    assert a["bytes_raygen"] == S * ray0 + S * 4                      # rays + the tile-order ids (no zero records: dep_bits)
+    assert a["bytes_accumulate"] == a["deposits"] * 16 + S // 8 + 96 * 96 * 2 * 16   # records with a set bit, the bits, the accumulator
     b = r.render_full(s).stats                                        # again, same workspace: same count
     assert b["deposits"] == a["deposits"]
     c = r.count_deposits(False).render_full(s).stats
