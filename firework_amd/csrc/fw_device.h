@@ -111,6 +111,7 @@ struct DFrame {
     uint32_t q_n_waves, q_shift;  // the batch's queue geometry (DQueue n_waves, cpw_shift): home slot <-> linear path id
     uint32_t skip_zero_deposits;  // black environment: k_shade writes only non-zero radiance records and sets their bit in dep_bits
     uint32_t *dep_bits;           // one bit per path slot (zeroed per batch): k_accumulate reads a record only where it is set
+    uint32_t hit4;                // 4-byte hit records (the code only): k_shade recomputes t.  Linear scan, scenes of spheres / rects / Rect3d only
     uint32_t pinhole0;            // aperture 0: every camera ray starts at cam_pos, segment-0 rays are stored as 16 B (direction only)
     float cam_pos[3];
 };
@@ -143,7 +144,7 @@ struct DPark {
 
 // Bytes per record of the streams above: what fw_stats.bytes_* (the layout's own algorithmic HBM bytes) are computed from,
 // kept next to the layout so that the two change together.
-constexpr uint32_t B_RAY = 24, B_RAY_PINHOLE0 = 16, B_STATE = 16, B_HIT = 8, B_DEPOSIT = 16, B_PARK = 40, B_ACCUM = 16;
+constexpr uint32_t B_RAY = 24, B_RAY_PINHOLE0 = 16, B_STATE = 16, B_HIT = 8, B_HIT4 = 4, B_DEPOSIT = 16, B_PARK = 40, B_ACCUM = 16;
 
 constexpr uint32_t MISS = 0xffffffffu;
 constexpr int MAX_SEGMENTS = 11;

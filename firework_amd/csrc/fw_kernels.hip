@@ -1094,7 +1094,8 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
             RngKey key{0, 0, 0};
             if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
             closest_hit<USE_BVH, USE_BVH>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj);
-            if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
+            if (!USE_BVH && f.hit4) reinterpret_cast<uint32_t *>(hits)[i] = __float_as_uint(pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y);   // the code alone: k_shade recomputes t
+            else if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
         }
         if (USE_BVH && sc.has_mesh) {
             unsigned long long mask = __ballot(deferred);
@@ -1654,8 +1655,32 @@ __device__ __forceinline__ void rect_hitinfo(uint32_t kind, float a_min, float a
     }
 }
 
-__device__ __forceinline__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, const Ray &world, float t, uint32_t prim, bool need_uv) {
+// The t of a recorded hit on a sphere, rectangle or Rect3d face, recomputed with the very expressions k_extend used (4-byte
+// hit records, DFrame.hit4).  A sphere's accepted root is t1 when t1 > t_min, else t2: the caller's t_max can only reject,
+// and had it rejected t1 it would have rejected the larger t2 as well (sphere.rs:40-47).
+__device__ __forceinline__ float recompute_t(const Obj &o, const Ray &r, uint32_t prim) {
+    const uint32_t kind = obj_kind(o);
+    if (kind == 0u) {
+        const float a = dot(r.d, r.d), b = 2.f * dot(r.o, r.d), c = dot(r.o, r.o) - o.q3.x * o.q3.x;
+        const float disc = b * b - 4.f * a * c;
+        const Rcp two_a = make_rcp(2.f * a);
+        if (disc == 0.f) return fdiv(-b, two_a);
+        const float sq = fsqrt(disc), t1 = fdiv(-b - sq, two_a);
+        return t1 > 0.001f ? t1 : fdiv(-b + sq, two_a);
+    }
+    float k = o.q4.x; uint32_t ot = kind == 1u ? 2u : (kind == 2u ? 1u : 0u);     // plane axis of XY / XZ / YZ
+    if (kind == 4u) {                                                             // rect3d.rs:19-77: faces +z -z +y -y +x -x
+        const float px = o.q3.x, py = o.q3.y, pz = o.q3.z, sx = o.q3.w, sy = o.q4.x, sz = o.q4.y;
+        const uint32_t ax = prim >> 1;
+        ot = ax == 0u ? 2u : (ax == 1u ? 1u : 0u);
+        k = ax == 0u ? ((prim & 1u) ? pz : pz + sz) : (ax == 1u ? ((prim & 1u) ? py : py + sy) : ((prim & 1u) ? px : px + sx));
+    }
+    return fdiv(k - comp(r.o, (int)ot), comp(r.d, (int)ot));
+}
+
+__device__ __forceinline__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, const Ray &world, float t, uint32_t prim, bool need_uv, bool hit4 = false) {
     Ray r = to_object_space(o, world);
+    if (hit4) t = recompute_t(o, r, prim);
     uint32_t kind = obj_kind(o), flags = obj_flags(o);
     HitInfo h; h.material = o.material; h.u = 0.f; h.v = 0.f;
     V3 p = ray_point(r, t), n = mk(0.f, 1.f, 0.f);
@@ -1758,7 +1783,7 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
         float4 m0 = matp[2 * o.material], m1 = matp[2 * o.material + 1];
         uint32_t mbits = __float_as_uint(m0.x), mkind = mbits & 0xffu, mtex = __float_as_uint(m0.y);
         bool need_uv = (mbits & MF_NEEDS_UV) != 0, tex_const = (mbits & MF_TEX_CONST) != 0;
-        HitInfo h = rebuild_hit(sc, o, r, t_hit, hit_code & ((1u << sc.prim_bits) - 1u), need_uv);
+        HitInfo h = rebuild_hit(sc, o, r, t_hit, hit_code & ((1u << sc.prim_bits) - 1u), need_uv, f.hit4 != 0u);
         V3 texc = mk(m1.x, m1.y, m1.z);                                      // inline ConstantTexture / Metal albedo
         if (!tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
         if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
@@ -1830,12 +1855,13 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     uint32_t out_n = 0;                                                  // survivors written so far (wave-uniform)
     // software pipeline: next chunk's ray / state / hit are in flight while the current chunk is shaded
     float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n; float2 rb_n = make_float2(0, 0), hr_n = rb_n;
-    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); st_n = load_state(in, base + lane, segment); hr_n = qld(&hits[base + lane]); }
+    auto load_hit = [&](uint32_t idx) { return f.hit4 ? make_float2(0.f, __uint_as_float(reinterpret_cast<const uint32_t *>(hits)[idx])) : qld(&hits[idx]); };
+    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); st_n = load_state(in, base + lane, segment); hr_n = load_hit(base + lane); }
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
         const uint32_t j = c0 + lane;
         const uint32_t i = base + j;
         float4 ra = ra_n, st = st_n; float2 rb = rb_n, hr = hr_n;
-        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); st_n = load_state(in, i + 64u, segment); hr_n = qld(&hits[i + 64u]); }
+        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); st_n = load_state(in, i + 64u, segment); hr_n = load_hit(i + 64u); }
         bool alive = false;
         Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
         if (j < n) {

@@ -326,6 +326,7 @@ struct fw_scene {
     DevBuf data;   // every scene array in one allocation (sections 256-byte aligned)
     uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mat = 0, n_tex = 0;
     uint32_t blas_pair_nodes = 0, tlas_pair_nodes = 0, max_tris = 0, n_tris = 0;
+    bool simple_shapes = false;   // every object is a sphere, an axis-aligned rect or a Rect3d (no medium, mesh, cone, cylinder, disk)
     bool hdr_env = false;
     ~fw_scene() {
         data.release();
@@ -737,6 +738,8 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.env.horizon[0] = e.horizon.x; d.env.horizon[1] = e.horizon.y; d.env.horizon[2] = e.horizon.z;
     d.env.hdr = hdr_dev; d.env.hdr_w = e.hdr_w; d.env.hdr_h = e.hdr_h;
     sc->hdr_env = e.kind == FW_ENV_HDR;
+    sc->simple_shapes = true;
+    for (uint32_t i = 0; i < desc->n_objects; i++) { uint32_t kf; std::memcpy(&kf, &objs[(size_t)i * fw::OBJ_Q * 4 + 3], 4); if ((kf & 0xffu) > 4u) sc->simple_shapes = false; }
     sc->tlas_nodes = ref_tlas_nodes; sc->blas_nodes = fl.ref_blas_nodes;   // reported: the reference topology (bvh.rs)
     sc->tlas_depth = tlas_p.depth; sc->blas_depth = fl.blas_depth;
     sc->blas_pair_nodes = fl.blas.count(); sc->tlas_pair_nodes = tlas_p.count(); sc->max_tris = fl.max_tris; sc->n_tris = (uint32_t)(fl.tri.size() / 12);
@@ -905,6 +908,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     fr.cam_pos[0] = cam.position[0]; fr.cam_pos[1] = cam.position[1]; fr.cam_pos[2] = cam.position[2];
     fr.pinhole0 = (cam.lens_radius == 0.f && cam.position[0] != 0.f && cam.position[1] != 0.f && cam.position[2] != 0.f &&
                    getenv("FIREWORK_NO_SHORT_RAYS") == nullptr) ? 1u : 0u;
+    // 4-byte hit records where k_shade can recompute t cheaply and exactly: the linear scan over spheres, rects and Rect3d
+    fr.hit4 = (!p->use_bvh && sc->simple_shapes && getenv("FIREWORK_NO_HIT4") == nullptr && !(getenv("FIREWORK_FUSED") && atoi(getenv("FIREWORK_FUSED")))) ? 1u : 0u;
     const fw::DEnv &env = sc->d.env;
     fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && getenv("FIREWORK_NO_ZERO_SKIP") == nullptr) ? 1u : 0u;
 
@@ -1033,7 +1038,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         stats->deposits = count_deposits ? deposits : stats->samples;      // every path ends exactly once (render.rs:19-31)
         {   // HBM bytes this layout moves (fw_device.h B_*): queue streams only, scene tables are cache-resident
             const uint64_t *R = stats->rays_per_depth;
-            const uint64_t S = stats->samples, ray0 = fr.pinhole0 ? fw::B_RAY_PINHOLE0 : fw::B_RAY;
+            const uint64_t S = stats->samples, ray0 = fr.pinhole0 ? fw::B_RAY_PINHOLE0 : fw::B_RAY, b_hit = fr.hit4 ? fw::B_HIT4 : fw::B_HIT;
             uint64_t rd_ray = R[0] * ray0, later = 0, survivors = 0;
             for (int s = 1; s < fw::MAX_SEGMENTS; s++) { rd_ray += R[s] * fw::B_RAY; later += R[s]; survivors += R[s]; }
             stats->bytes_raygen = S * ray0 + (fr.pixel_ids ? S * 4 : 0);
@@ -1041,8 +1046,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             const uint64_t shade_in = rd_ray + later * fw::B_STATE, shade_out = survivors * (fw::B_RAY + fw::B_STATE) + stats->deposits * fw::B_DEPOSIT;
             if (fused) { stats->bytes_extend = 0; stats->bytes_shade = shade_in + shade_out; }
             else {
-                stats->bytes_extend = rd_ray + medium + stats->rays * fw::B_HIT + stats->parked_rays * 2 * fw::B_PARK;
-                stats->bytes_shade = shade_in + stats->rays * fw::B_HIT + shade_out;
+                stats->bytes_extend = rd_ray + medium + stats->rays * b_hit + stats->parked_rays * 2 * fw::B_PARK;
+                stats->bytes_shade = shade_in + stats->rays * b_hit + shade_out;
             }
             stats->bytes_accumulate = (fr.skip_zero_deposits ? stats->deposits * fw::B_DEPOSIT + S / 8 : S * fw::B_DEPOSIT) + (uint64_t)n_batches * n_pix * 2 * fw::B_ACCUM;
         }

@@ -185,8 +185,8 @@ def test_stats_carry_the_layouts_own_bytes_and_the_deposits_really_written():
     assert 0 < a["deposits"] < S                                      # most cornell paths end black
     later, ray0 = sum(R[1:]), 16                                      # pinhole camera: segment-0 rays are 16 B
     rd_ray = R[0] * ray0 + later * 24
-    assert a["bytes_extend"] == rd_ray + 8 * a["rays"]
-    assert a["bytes_shade"] == rd_ray + later * 16 + 8 * a["rays"] + later * 40 + a["deposits"] * 16
+    assert a["bytes_extend"] == rd_ray + 4 * a["rays"]                # 4-byte hit records: spheres, rects and boxes only (hit4)
+    assert a["bytes_shade"] == rd_ray + later * 16 + 4 * a["rays"] + later * 40 + a["deposits"] * 16
     assert a["bytes_raygen"] == S * ray0 + S * 4                      # rays + the tile-order ids (no zero records: dep_bits)
     assert a["bytes_accumulate"] == a["deposits"] * 16 + S // 8 + 96 * 96 * 2 * 16   # records with a set bit, the bits, the accumulator
     b = r.render_full(s).stats                                        # again, same workspace: same count
@@ -197,6 +197,8 @@ def test_stats_carry_the_layouts_own_bytes_and_the_deposits_really_written():
     s2, r2 = scenes.config("C4b_volume_test", 64, 64, 8)
     d = r2.count_deposits(True).render_full(s2).stats
     assert d["deposits"] == d["samples"]
+    R2 = d["rays_per_depth"]                                          # a medium: 8-byte hit records (t is drawn, not recomputable)
+    assert d["bytes_extend"] >= R2[0] * 16 + sum(R2[1:]) * 24 + 8 * d["rays"]
     # parked rays are counted where a mesh is walked by k_blas
     s3, r3 = scenes.config("C3_suzanne", 96, 54, 8)
     e = r3.render_full(s3).stats
