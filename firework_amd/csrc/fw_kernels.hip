@@ -733,7 +733,11 @@ static_assert(FW_WB == 64, "the parked-ray list and the wave-private queues assu
 // (Tried on the L2-fetching walks too — several consecutive queues per wave, statically dealt or taken from a device-wide
 // atomic: the busy lanes of suzanne's k_blas node loop rose from 55 to 80 %, wave-iterations fell 29 %, and the kernel got
 // SLOWER, 10.2 -> 15.4 / 11.7 ms: those walks are bound by their node gathers, runs of neighbouring queues are unevenly
-// loaded, and the extra registers cost a wave per SIMD.  They keep one queue per wave.)
+// loaded, and the extra registers cost a wave per SIMD.  They keep one queue per wave.
+// Also tried here: ONE device-wide counter instead of one per workgroup, so that no CU idles while another still has
+// queues (the LDS walks average 2.4-2.8 of 4 waves per SIMD): suzanne @64 11.1 -> 13.4 ms, part2 @16 10.4 -> 12.6 ms — a
+// device-scope atomic per queue from 4 096 waves on one address is slow, and the early-finishing CUs were not idle: they
+// run the other batch's k_shade / k_extend_scan.)
 struct BlockStream {
     // the wave's queues are named by an index k: queue id = q_off + k * q_mul (k-ranges are dealt statically or taken from a counter)
     uint32_t q, q_end, q0;     // next index to open; end and start of this wave's static range
