@@ -1127,7 +1127,10 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
 #endif
 template <bool PARK>
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVES, 8))) void k_extend_scan(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment,
-                                                    int tlas_levels, DPark park) {
+                                                    int tlas_levels, float4 *__restrict__ park_a, float2 *__restrict__ park_b, float4 *__restrict__ park_m,
+                                                    uint32_t *__restrict__ park_count, uint32_t park_stride) {
+    // the park arrays are `__restrict__` kernel arguments, not a DPark: only then can the compiler prove that the stores
+    // into them leave the scene tables alone, and read the (wave-uniform) object records with scalar loads
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     if (w >= q.n_waves) return;
     const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w];
@@ -1174,16 +1177,16 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVE
             if (pmask) {
                 const uint32_t prank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pmask, 0u));
                 if (deferred) {
-                    const uint32_t e = w * park.stride + park_n + prank;
-                    qst(&park.ray_a[e], make_float4(r.o.x, r.o.y, r.o.z, r.d.x));
-                    qst(&park.ray_b[e], make_float2(r.d.y, r.d.z));
-                    qst(&park.meta[e], make_float4(__uint_as_float(i), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
+                    const uint32_t e = w * park_stride + park_n + prank;
+                    qst(&park_a[e], make_float4(r.o.x, r.o.y, r.o.z, r.d.x));
+                    qst(&park_b[e], make_float2(r.d.y, r.d.z));
+                    qst(&park_m[e], make_float4(__uint_as_float(i), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
                 }
                 park_n += (uint32_t)__popcll(pmask);
             }
         }
     }
-    if (PARK && lane == 0) park.pcount[w] = park_n;
+    if (PARK && lane == 0) park_count[w] = park_n;
 }
 
 // (Round 2 tried to DEFER the expensive shapes of the linear scan: cornell's two rotated boxes are 12 of a ray's 18 rectangle
@@ -2148,7 +2151,7 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     const dim3 sg = eg;
     if (use_bvh && c.tlas_refill && c.has_mesh) {
         // TLAS walk that parks mesh rays in HBM, then their BLAS walks; a medium around a mesh still walks it in place (blas levels)
-        if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<true>, eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park);
+        if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<true>, eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park.ray_a, park.ray_b, park.meta, park.pcount, park.stride);
         else hipLaunchKernelGGL(k_extend_tlas_park, sg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
         // the whole BLAS in LDS when it fits next to sixteen 16-bit stacks (k_blas_lds), else node fetches from L2 (k_blas)
         const uint32_t bl = (uint32_t)c.blas_depth + 1u;
@@ -2174,7 +2177,7 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
             hipLaunchKernelGGL(k_extend_tlas_lds, dim3(std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES)), dim3(LDS_WAVES * 64), lds_tlas, c.stream,
                                sc, f, in, hits, c.q, segment, c.tlas_pair_nodes, (uint32_t)tl);
         }
-        else if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, DPark{});
+        else if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, (float4 *)nullptr, (float2 *)nullptr, (float4 *)nullptr, (uint32_t *)nullptr, 0u);
         else hipLaunchKernelGGL(k_extend_tlas, sg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     }
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
