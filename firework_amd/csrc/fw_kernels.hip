@@ -584,6 +584,13 @@ __device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, 
     bool hl = hit_aabb_entry(q0, q1, o, inv, tmin, tmax, tl), hr = hit_aabb_entry(q2, q3, o, inv, tmin, tmax, tr);
     hl = hl && !(tl > cull); hr = hr && !(tr > cull);
     const uint32_t rl = __float_as_uint(q0.w), rr = __float_as_uint(q1.w);
+#if FW_FLAT_STEP
+    const bool left_first = tl <= tr;
+    uint32_t next = (hl && (!hr || left_first)) ? rl : rr;
+    if (hl && hr) st.push(left_first ? rr : rl);
+    if (!hl && !hr) { next = REF_DONE; if (st.sp) next = st.pop(); }
+    return next;
+#else
     if (hl && hr) {
         const bool left_first = tl <= tr;
         st.push(left_first ? rr : rl);
@@ -592,6 +599,7 @@ __device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, 
     if (hl) return rl;
     if (hr) return rr;
     return st.sp ? st.pop() : REF_DONE;
+#endif
 }
 // best t -> culling bound, a little beyond it whatever its sign (a medium's inner mesh is walked with t in (-MAX, MAX))
 __device__ __forceinline__ float cull_bound(float t) { return t + fabsf(t) * 1e-6f; }
@@ -1842,19 +1850,20 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
 
 extern __shared__ float4 lds_tables[];
 
-template <bool LDS_TAB>
+template <int LDS_TAB>   // 1: object + material + texture tables staged in LDS; 2: materials + textures only (part2: 1 409 objects are 135 KB, its 10 materials are not); 0: none
 __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DPaths out, const float2 *__restrict__ hits,
                                                  float4 *__restrict__ sample_rad, DQueue q, int segment,
                                                  uint32_t n_mat, uint32_t n_tex) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     const float4 *objp = sc.obj, *matp = sc.mat, *texp = sc.tex;
     if (LDS_TAB) {
-        const uint32_t no = sc.n_objects * OBJ_Q, nm = 2 * n_mat, nt = 2 * n_tex;
-        for (uint32_t k = threadIdx.x; k < no; k += WB) lds_tables[k] = sc.obj[k];
+        const uint32_t no = LDS_TAB == 1 ? sc.n_objects * OBJ_Q : 0u, nm = 2 * n_mat, nt = 2 * n_tex;
+        if (LDS_TAB == 1) for (uint32_t k = threadIdx.x; k < no; k += WB) lds_tables[k] = sc.obj[k];
         for (uint32_t k = threadIdx.x; k < nm; k += WB) lds_tables[no + k] = sc.mat[k];
         for (uint32_t k = threadIdx.x; k < nt; k += WB) lds_tables[no + nm + k] = sc.tex[k];
         __syncthreads();
-        objp = lds_tables; matp = lds_tables + no; texp = lds_tables + no + nm;
+        if (LDS_TAB == 1) objp = lds_tables;
+        matp = lds_tables + no; texp = lds_tables + no + nm;
     }
     if (w >= q.n_waves) return;
     const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w];
@@ -2186,10 +2195,14 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment) {
     size_t tab = ((size_t)sc.n_objects * OBJ_Q + 2 * (size_t)c.n_mat + 2 * (size_t)c.n_tex) * sizeof(float4);
+    const size_t tab_mt = (2 * (size_t)c.n_mat + 2 * (size_t)c.n_tex) * sizeof(float4);
     if (c.lds_tables && tab <= LDS_TABLE_LIMIT)
-        hipLaunchKernelGGL(k_shade<true>, wave_grid(c), dim3(WB), tab, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
+        hipLaunchKernelGGL(k_shade<1>, wave_grid(c), dim3(WB), tab, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
+    else if (c.lds_tables && tab_mt <= LDS_TABLE_LIMIT)   // the two dependent fetches behind the object record come from LDS (part2 k_shade 6.7 -> 6.55 ms;
+        // a leaner per-kind object fetch on top — 3 loads instead of 6 for an unrotated sphere — did not pay: 6.8 ms)
+        hipLaunchKernelGGL(k_shade<2>, wave_grid(c), dim3(WB), tab_mt, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
     else
-        hipLaunchKernelGGL(k_shade<false>, wave_grid(c), dim3(WB), 0, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
+        hipLaunchKernelGGL(k_shade<0>, wave_grid(c), dim3(WB), 0, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
 }
 void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, float4 *sample_rad,
                    int segment, bool use_bvh) {
