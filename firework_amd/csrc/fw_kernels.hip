@@ -584,22 +584,14 @@ __device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, 
     bool hl = hit_aabb_entry(q0, q1, o, inv, tmin, tmax, tl), hr = hit_aabb_entry(q2, q3, o, inv, tmin, tmax, tr);
     hl = hl && !(tl > cull); hr = hr && !(tr > cull);
     const uint32_t rl = __float_as_uint(q0.w), rr = __float_as_uint(q1.w);
-#if FW_FLAT_STEP
+    // Flat, not nested: one predicated push and one predicated pop around a select.  The nested form (both -> push and return,
+    // else left, else right, else pop) cost the walk loops four extra scalar mask copies per step and made the compiler wait
+    // for the node's first quad before issuing the loads of the other three (part2 @16 10.35 -> 10.15 ms, suzanne @64 10.3 -> 10.2).
     const bool left_first = tl <= tr;
     uint32_t next = (hl && (!hr || left_first)) ? rl : rr;
     if (hl && hr) st.push(left_first ? rr : rl);
     if (!hl && !hr) { next = REF_DONE; if (st.sp) next = st.pop(); }
     return next;
-#else
-    if (hl && hr) {
-        const bool left_first = tl <= tr;
-        st.push(left_first ? rr : rl);
-        return left_first ? rl : rr;
-    }
-    if (hl) return rl;
-    if (hr) return rr;
-    return st.sp ? st.pop() : REF_DONE;
-#endif
 }
 // best t -> culling bound, a little beyond it whatever its sign (a medium's inner mesh is walked with t in (-MAX, MAX))
 __device__ __forceinline__ float cull_bound(float t) { return t + fabsf(t) * 1e-6f; }
