@@ -85,6 +85,7 @@ struct DScene {
     uint32_t n_objects;
     uint32_t tlas_root;       // root reference of the TLAS (a pair node, or REF_LEAF | object for a one-object scene)
     uint32_t has_medium;
+    uint32_t has_perlin;          // some texture is PerlinNoise / Turbulence / Marble: k_shade stages the permutation table in LDS
     uint32_t has_mesh;
     uint32_t prim_bits;       // hit code = object << prim_bits | primitive
     uint32_t n_hoisted;       // objects kept OUT of the walked TLAS because nearly every ray meets their box (part2's fog sphere

@@ -1395,6 +1395,9 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
             if (walking) cur = pair_step(lds_nodes, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
+            // two steps per exit check: the ballot, the count and the exit rule cost a third of a step's issue time
+            // (suzanne @64 10.1 -> 9.9 ms; the TLAS walk of part2 gains nothing from the same and keeps one)
+            if (act && !(cur & REF_LEAF)) cur = pair_step(lds_nodes, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
         }
         if (act && (cur & REF_LEAF)) {
             if (cur != REF_DONE) {
@@ -1533,7 +1536,7 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
 // ------------------------------------------------------------------------------------------------
 // K5/K6  shading: textures, materials, environment
 // ------------------------------------------------------------------------------------------------
-__constant__ uint8_t PERM[256] = {   // texture.rs:80-106
+__constant__ __attribute__((aligned(4))) uint8_t PERM[256] = {   // texture.rs:80-106
     151, 160, 137, 91, 90, 15, 131, 13, 201, 95, 96, 53, 194, 233, 7, 225, 140, 36, 103, 30, 69, 142, 8, 99, 37, 240, 21, 10,
     23, 190, 6, 148, 247, 120, 234, 75, 0, 26, 197, 62, 94, 252, 219, 203, 117, 35, 11, 32, 57, 177, 33, 88, 237, 149, 56, 87,
     174, 20, 125, 136, 171, 168, 68, 175, 74, 165, 71, 134, 139, 48, 27, 166, 77, 146, 158, 231, 83, 111, 229, 122, 60, 211,
@@ -1544,7 +1547,15 @@ __constant__ uint8_t PERM[256] = {   // texture.rs:80-106
     178, 185, 112, 104, 218, 246, 97, 228, 251, 34, 242, 193, 238, 210, 144, 12, 191, 179, 162, 241, 81, 51, 145, 235, 249,
     14, 239, 107, 49, 192, 214, 31, 181, 199, 106, 157, 184, 84, 204, 176, 115, 121, 50, 45, 127, 4, 150, 254, 138, 236, 205,
     93, 222, 114, 67, 29, 24, 72, 243, 141, 128, 195, 78, 66, 215, 61, 156, 180};
-__device__ __forceinline__ uint32_t P(uint32_t i) { return PERM[i & 255u]; }
+// Perlin's lattice walk is three dependent table reads deep and a turbulence texture runs it seven times: from
+// __constant__ memory with per-lane indices each read is a vector load from L2 (~1 us under load), 21 in a row for the
+// few lanes of a wave that hit such a texture while the others wait.  k_shade / k_bounce copy the table into LDS first
+// (stage_perm) when the scene has such a texture: part2's k_shade 6.7 -> 5.7 ms, the frame @16 spp 10.19 -> 9.72 ms.
+__shared__ uint8_t lds_perm[256];
+__device__ __forceinline__ void stage_perm() {     // all threads of the workgroup; the caller's barrier publishes it
+    for (uint32_t k = threadIdx.x; k < 64u; k += blockDim.x) reinterpret_cast<uint32_t *>(lds_perm)[k] = reinterpret_cast<const uint32_t *>(PERM)[k];
+}
+__device__ __forceinline__ uint32_t P(uint32_t i) { return lds_perm[i & 255u]; }
 // Rust `f32 as usize & 255`: saturating cast (negatives and NaN -> 0, huge -> usize::MAX -> 255)
 __device__ __forceinline__ uint32_t lattice(float fl) {
     if (!(fl > 0.f)) return 0u;
@@ -1843,11 +1854,19 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
 extern __shared__ float4 lds_tables[];
 
 template <int LDS_TAB>   // 1: object + material + texture tables staged in LDS; 2: materials + textures only (part2: 1 409 objects are 135 KB, its 10 materials are not); 0: none
+// 5 waves per SIMD (96 VGPRs, no spills) instead of the compiler's 4 (114): nothing while the scattered zero deposits bound
+// the kernel (round 1), now cornell k_shade 20.55 -> 20.13 ms (four interleaved pairs), hdri 5.84 -> 5.56, suzanne 4.74 -> 4.57;
+// 6 waves (80 VGPRs) spill three registers and gain nothing more.
+#ifndef FW_SHADE_WAVES
+#define FW_SHADE_WAVES 5
+#endif
+__attribute__((amdgpu_waves_per_eu(FW_SHADE_WAVES, 8)))
 __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DPaths out, const float2 *__restrict__ hits,
                                                  float4 *__restrict__ sample_rad, DQueue q, int segment,
                                                  uint32_t n_mat, uint32_t n_tex) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     const float4 *objp = sc.obj, *matp = sc.mat, *texp = sc.tex;
+    if (sc.has_perlin) { stage_perm(); if (!LDS_TAB) __syncthreads(); }
     if (LDS_TAB) {
         const uint32_t no = LDS_TAB == 1 ? sc.n_objects * OBJ_Q : 0u, nm = 2 * n_mat, nt = 2 * n_tex;
         if (LDS_TAB == 1) for (uint32_t k = threadIdx.x; k < no; k += WB) lds_tables[k] = sc.obj[k];
@@ -1907,6 +1926,7 @@ __global__ __launch_bounds__(WB) void k_bounce(DScene sc, DFrame f, DPaths in, D
                                                   uint32_t table_quads) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     const float4 *objp = sc.obj, *matp = sc.mat, *texp = sc.tex;
+    if (sc.has_perlin) { stage_perm(); if (!LDS_TAB) __syncthreads(); }
     if (LDS_TAB) {
         const uint32_t no = sc.n_objects * OBJ_Q, nm = 2 * n_mat, nt = 2 * n_tex;
         for (uint32_t k = threadIdx.x; k < no; k += WB) lds_tables[k] = sc.obj[k];

@@ -490,7 +490,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     Flattener fl{desc};
     std::vector<float> objs((size_t)desc->n_objects * fw::OBJ_Q * 4, 0.f);
     std::vector<Box> world(desc->n_objects), true_world(desc->n_objects);
-    bool has_medium = false;
+    bool has_medium = false, has_perlin = false;
     for (uint32_t i = 0; i < desc->n_objects; i++) {
         const fw_object &o = desc->objects[i];
         ShapeParams sp;
@@ -613,7 +613,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         case FW_TEX_CHECKER:
             if (t.odd < 0 || t.even < 0 || (uint32_t)t.odd >= desc->n_textures || (uint32_t)t.even >= desc->n_textures) return fail(FW_ERR_BAD_ARG, "checker child texture out of range");
             q[3] = bits_f((uint32_t)t.odd); q[4] = bits_f((uint32_t)t.even); break;
-        case FW_TEX_PERLIN: case FW_TEX_TURBULENCE: case FW_TEX_MARBLE: break;
+        case FW_TEX_PERLIN: case FW_TEX_TURBULENCE: case FW_TEX_MARBLE: has_perlin = true; break;
         case FW_TEX_IMAGE: {
             if (!t.img_rgb8 || !t.img_w || !t.img_h) return fail(FW_ERR_BAD_ARG, "ImageTexture without pixels");
             size_t off = images.size(), nb = (size_t)t.img_w * t.img_h * 3;
@@ -728,7 +728,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.mat = (const float4 *)(base + secs[8].off); d.tex = (const float4 *)(base + secs[9].off); d.images = base + secs[10].off;
     const float *hdr_dev = (const float *)(base + secs[11].off);
     d.obj_cull = (const float4 *)(base + secs[12].off);
-    d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
+    d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_perlin = has_perlin ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
     d.prim_bits = prim_bits; d.tlas_root = tlas_root;
     d.n_hoisted = (uint32_t)hoisted.size();
     for (size_t i = 0; i < 4; i++) d.hoisted[i] = i < hoisted.size() ? hoisted[i] : 0u;
