@@ -8,6 +8,7 @@
 #define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
 template <int OP> __global__ void k(float *out, float fs) {
     float a[8], b = fs * 0.5f + 1.f, c = fs * 0.25f + 0.5f;
+    unsigned long long d[8]; for (int i = 0; i < 8; i++) d[i] = threadIdx.x + i;
     for (int i = 0; i < 8; i++) a[i] = fs + threadIdx.x + i;
 #pragma unroll 1
     for (int it = 0; it < N_ITER; it++) {
@@ -30,6 +31,9 @@ template <int OP> __global__ void k(float *out, float fs) {
 #define RCP(i) asm volatile("v_rcp_f32_e32 %0, %0" : "+v"(a[i]));
 #define XOR(i) asm volatile("v_xor_b32_e32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
 #define MULLO(i) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(a[i]) : "v"(b));
+#define MAD64(i) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(d[i]) : "v"(b), "v"(c) : "vcc");
+#define XSDWA(i) asm volatile("v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(a[i]));
+#define CVTU(i) asm volatile("v_cvt_f32_u32_e32 %0, %0" : "+v"(a[i]));
 #define SMOV(i) asm volatile("s_mov_b32 s12, s13" : : : "s12");
 #define SAND(i) asm volatile("s_and_b64 s[14:15], s[10:11], exec" : : : "s14", "s15", "scc");
 #define MIXVS(i) asm volatile("v_mul_f32_e32 %0, %1, %0\n s_and_b64 s[14:15], s[10:11], exec" : "+v"(a[i]) : "v"(b) : "s14", "s15", "scc");
@@ -39,8 +43,9 @@ template <int OP> __global__ void k(float *out, float fs) {
         if (OP == 12) { REP8(CMP3) } if (OP == 13) { REP8(CMP2) } if (OP == 14) { REP8(MOV) } if (OP == 15) { REP8(FIX) }
         if (OP == 16) { REP8(RCP) } if (OP == 17) { REP8(XOR) } if (OP == 18) { REP8(MULLO) } if (OP == 19) { REP8(SMOV) }
         if (OP == 20) { REP8(SAND) } if (OP == 21) { REP8(MIXVS) }
+        if (OP == 22) { REP8(MAD64) } if (OP == 23) { REP8(XSDWA) } if (OP == 24) { REP8(CVTU) }
     }
-    float s = 0; for (int i = 0; i < 8; i++) s += a[i];
+    float s = 0; for (int i = 0; i < 8; i++) s += a[i] + (float)d[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 template <int OP> void run(const char *name, int waves_per_simd) {
@@ -63,5 +68,6 @@ int main() {
     RUN(10, "v_cndmask_b32_e64 (sgpr mask)") RUN(11, "v_cndmask_b32_e32 (vcc)") RUN(12, "v_cmp_gt_f32_e64 -> sgpr") RUN(13, "v_cmp_gt_f32_e32 -> vcc")
     RUN(14, "v_mov_b32") RUN(15, "v_div_fixup_f32") RUN(16, "v_rcp_f32") RUN(17, "v_xor_b32") RUN(18, "v_mul_lo_u32") RUN(19, "s_mov_b32") RUN(20, "s_and_b64")
     RUN(21, "v_mul_f32 + s_and_b64 pair (per pair)")
+    RUN(22, "v_mad_u64_u32") RUN(23, "v_xor_b32_sdwa") RUN(24, "v_cvt_f32_u32")
     return 0;
 }
