@@ -111,6 +111,7 @@ struct DFrame {
     float inv_n_pixels;           // 1.0f / n_pixels (path_id -> sample index without an integer division)
     uint32_t q_n_waves, q_shift;  // the batch's queue geometry (DQueue n_waves, cpw_shift): home slot <-> linear path id
     uint32_t skip_zero_deposits;  // black environment: k_shade writes only non-zero radiance records and sets their bit in dep_bits
+    uint32_t dep_pixel_major;     // dep_bits is indexed p_local * spp_batch + s_local (small pixel sets) instead of by home slot
     uint32_t *dep_bits;           // one bit per path slot (zeroed per batch): k_accumulate reads a record only where it is set
     uint32_t hit4;                // 4-byte hit records (the code only): k_shade recomputes t.  Linear scan, scenes of spheres / rects / Rect3d only
     uint32_t pinhole0;            // aperture 0: every camera ray starts at cam_pos, segment-0 rays are stored as 16 B (direction only)

@@ -159,6 +159,22 @@ __device__ __forceinline__ RngKey key_of_linear(const DFrame &f, uint32_t linear
     k.seed32 = f.seed32;
     return k;
 }
+// Bit of a path in DFrame.dep_bits ("this path wrote a radiance record") in the PIXEL-major layout, p_local * spp_batch +
+// s_local: one pixel's samples are consecutive bits and k_accumulate reads them as a few words (the records themselves stay
+// at the path's home slot).  Used for small pixel sets (DFrame.dep_pixel_major: a rank's share of a tiled frame), where
+// k_accumulate has too few threads to hide a chain of one bit-word load per sample (1/8 of cornell: 0.47 -> 0.13 ms, the
+// rank's frame 6.5 -> 6.1 ms); a whole frame keeps the slot-major bits, bit = home slot, which cost k_shade nothing to address
+// (the decode below is 12 instructions in a kernel that is bound by them: +0.3 ms per cornell frame) and leave k_accumulate
+// bound by its 16-byte record gathers out of a multi-GB array either way (0.5-0.6 ms from 1/4 of the frame upwards).
+__device__ __forceinline__ uint32_t dep_bit_of(const DFrame &f, uint32_t home) {
+    const uint32_t lane = home & 63u, c = (home >> 6) & ((1u << f.q_shift) - 1u), w = home >> (f.q_shift + 6u);
+    const uint32_t linear = (c * f.q_n_waves + w) * 64u + lane;
+    uint32_t s_local = (uint32_t)((float)linear * f.inv_n_pixels);
+    int32_t p_local = (int32_t)(linear - s_local * f.n_pixels);
+    if (p_local < 0) { s_local--; p_local += (int32_t)f.n_pixels; }
+    else if ((uint32_t)p_local >= f.n_pixels) { s_local++; p_local -= (int32_t)f.n_pixels; }
+    return (uint32_t)p_local * f.spp_batch + s_local;
+}
 __device__ __forceinline__ RngKey key_of(const DFrame &f, uint32_t home) {
     const uint32_t lane = home & 63u, c = (home >> 6) & ((1u << f.q_shift) - 1u), w = home >> (f.q_shift + 6u);
     return key_of_linear(f, (c * f.q_n_waves + w) * 64u + lane);
@@ -1846,7 +1862,10 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
     if (!alive && !(f.skip_zero_deposits && rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
         if (FW_NT_RAD) st_nt(&sample_rad[path_id], make_float4(rad.x, rad.y, rad.z, 0.f));
         else sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, 0.f);
-        if (f.skip_zero_deposits) atomicOr(&f.dep_bits[path_id >> 5], 1u << (path_id & 31u));   // "this slot holds a record" (3.6 % of cornell's paths)
+        if (f.skip_zero_deposits) {                                  // "this path wrote a record" (3.6 % of cornell's paths)
+            const uint32_t b = f.dep_pixel_major ? dep_bit_of(f, path_id) : path_id;
+            atomicOr(&f.dep_bits[b >> 5], 1u << (b & 31u));
+        }
     }
     return alive;
 }
@@ -2023,16 +2042,43 @@ __global__ __launch_bounds__(WB) void k_accumulate(DFrame f, const float4 *__res
         if (f.skip_zero_deposits) {
             // black environment: only the slots whose bit is set hold a record (k_shade), all others contribute an exact +0:
             // 1 bit instead of 16 bytes per sample is read, and nobody had to write the zeros
-            for (; s + 16u <= f.spp_batch; s += 16u) {
-                uint32_t h[16], bw[16];
+            if (!f.dep_pixel_major) {     // slot-major bits (whole frames): the word of sample s is that of its home slot
+                for (; s + 16u <= f.spp_batch; s += 16u) {
+                    uint32_t h[16], bw[16];
 #pragma unroll
-                for (int k = 0; k < 16; k++) { h[k] = home_then_advance(); bw[k] = f.dep_bits[h[k] >> 5]; }
+                    for (int k = 0; k < 16; k++) { h[k] = home_then_advance(); bw[k] = f.dep_bits[h[k] >> 5]; }
 #pragma unroll
-                for (int k = 0; k < 16; k++) if ((bw[k] >> (h[k] & 31u)) & 1u) { const float4 v = sample_rad[h[k]]; a.x += v.x; a.y += v.y; a.z += v.z; }
+                    for (int k = 0; k < 16; k++) if ((bw[k] >> (h[k] & 31u)) & 1u) { const float4 v = sample_rad[h[k]]; a.x += v.x; a.y += v.y; a.z += v.z; }
+                }
+                for (; s < f.spp_batch; s++) {
+                    const uint32_t h = home_then_advance();
+                    if ((f.dep_bits[h >> 5] >> (h & 31u)) & 1u) { const float4 v = sample_rad[h]; a.x += v.x; a.y += v.y; a.z += v.z; }
+                }
+                accum[p] = a;
+                continue;
             }
-            for (; s < f.spp_batch; s++) {
-                const uint32_t h = home_then_advance();
-                if ((f.dep_bits[h >> 5] >> (h & 31u)) & 1u) { const float4 v = sample_rad[h]; a.x += v.x; a.y += v.y; a.z += v.z; }
+            // pixel-major bits (dep_bit_of): the pixel's bits are [p * spp, (p + 1) * spp) — eight words per round trip, then
+            // one record per set bit, in sample order
+            const uint32_t b0 = p * f.spp_batch, b1 = b0 + f.spp_batch, j_last = (b1 - 1u) >> 5;
+            for (uint32_t j0 = b0 >> 5; j0 <= j_last; j0 += 8u) {
+                uint32_t wd[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) wd[k] = (j0 + k <= j_last) ? f.dep_bits[j0 + k] : 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 8u; k++) {
+                    const uint32_t j = j0 + k;
+                    uint32_t word = wd[k];
+                    if (j == (b0 >> 5)) word &= ~0u << (b0 & 31u);
+                    if (j == (b1 >> 5)) word &= (1u << (b1 & 31u)) - 1u;
+                    while (word) {
+                        const uint32_t bit = (uint32_t)__ffs((int)word) - 1u;
+                        word &= word - 1u;
+                        const uint32_t lin = (j * 32u + bit - b0) * f.n_pixels + p;       // s_local * n_pixels + p
+                        const uint32_t g = lin >> 6, cc = g / f.q_n_waves, ww = g - cc * f.q_n_waves;
+                        const float4 v = sample_rad[(ww << (f.q_shift + 6u)) | (cc << 6) | (lin & 63u)];
+                        a.x += v.x; a.y += v.y; a.z += v.z;
+                    }
+                }
             }
             accum[p] = a;
             continue;

@@ -911,6 +911,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // 4-byte hit records where k_shade can recompute t cheaply and exactly: the linear scan over spheres, rects and Rect3d
     fr.hit4 = (!p->use_bvh && sc->simple_shapes && getenv("FIREWORK_NO_HIT4") == nullptr && !(getenv("FIREWORK_FUSED") && atoi(getenv("FIREWORK_FUSED")))) ? 1u : 0u;
     const fw::DEnv &env = sc->d.env;
+    fr.dep_pixel_major = (n_pix <= 65536u && getenv("FIREWORK_DEP_SLOT_MAJOR") == nullptr) || getenv("FIREWORK_DEP_PIXEL_MAJOR") != nullptr ? 1u : 0u;
     fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && getenv("FIREWORK_NO_ZERO_SKIP") == nullptr) ? 1u : 0u;
 
     // per-launch timing (FW_FLAG_TIME_KERNELS): one event after every launch on the launch's own stream; the end of

@@ -301,6 +301,26 @@ def test_fused_bounce_kernel_is_bit_identical_to_the_split_kernels(monkeypatch):
         assert np.array_equal(split.linear, fused.linear) and split.stats["rays"] == fused.stats["rays"]
 
 
+def test_deposit_bitmap_layouts_and_hit_record_sizes_are_bit_identical(monkeypatch):
+    """Over a black environment k_shade marks the paths that wrote a radiance record in a bitmap that is slot-major for whole
+    frames and pixel-major for small pixel sets (DFrame.dep_pixel_major); scenes of spheres, rects and boxes get 4-byte hit
+    records with t recomputed in k_shade (DFrame.hit4).  Each switch forced both ways: same bits, same deposit counts."""
+    for w, h, spp in ((96, 96, 33), (50, 31, 7)):                    # spp not a multiple of 32: a pixel's bits straddle words
+        s, r = scenes.config("C2_cornell_box", w, h, spp)
+        r.count_deposits(True)
+        frames = []
+        for env in ({}, {"FIREWORK_DEP_SLOT_MAJOR": "1"}, {"FIREWORK_DEP_PIXEL_MAJOR": "1"}, {"FIREWORK_NO_HIT4": "1"}):
+            for k in ("FIREWORK_DEP_SLOT_MAJOR", "FIREWORK_DEP_PIXEL_MAJOR", "FIREWORK_NO_HIT4"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            frames.append(r.render_full(s))
+        for f in frames[1:]:
+            assert np.array_equal(f.linear, frames[0].linear) and f.stats["deposits"] == frames[0].stats["deposits"]
+            assert f.stats["rays_per_depth"] == frames[0].stats["rays_per_depth"]
+        assert frames[3].stats["bytes_shade"] > frames[0].stats["bytes_shade"]      # 8-byte hit records
+
+
 def test_errors_cross_the_abi_as_codes():
     from firework_amd import _abi as A
     r = Renderer.default().width(8).height(8).samples(1)

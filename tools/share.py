@@ -11,7 +11,7 @@ renderer.time_kernels(True)
 base = None
 for world in [int(x) for x in os.environ.get("SHARE_WORLDS", "1,2,4,8").split(",")]:
     tr = TiledRenderer(scene, renderer, 0, world, 0, dist=None)
-    tr.tg.world = 1   # no collective: assemble() just scatters the local tiles
+    tr.tg.world = 1; tr.tg.collective = False   # no collective: assemble() just scatters the local tiles
     tr.tg.all_ids_dev = [tr.tg.all_ids_dev[0]]
     for _ in range(2): tr.render_frame()
     torch.cuda.synchronize(); t0 = time.perf_counter()
