@@ -1138,6 +1138,9 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
 // floor, light).  Its own kernel since round 2: inside the one body of all BVH entry points it shared their 96 registers
 // (5 waves per SIMD) although it only streams rays through a few wave-uniform tests and waits for HBM.
 // ------------------------------------------------------------------------------------------------
+#ifndef FW_DEFER_WAVES
+#define FW_DEFER_WAVES 7
+#endif
 #ifndef FW_SCAN_WAVES
 #define FW_SCAN_WAVES 6
 #endif
@@ -1205,7 +1208,117 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVE
     if (PARK && lane == 0) park_count[w] = park_n;
 }
 
-// (Round 2 tried to DEFER the expensive shapes of the linear scan: cornell's two rotated boxes are 12 of a ray's 18 rectangle
+// ------------------------------------------------------------------------------------------------
+// K2-lin'  k_extend_linear_defer: the linear scan with its trailing Rect3d objects taken out of the per-ray loop.
+//
+// cornell's two rotated boxes are 12 of a ray's 18 rectangle tests, and a bounce ray can reach either only about one time in
+// four — but its 64 lanes never all miss, so the wave pays for both boxes for every ray.  Here a ray runs the other objects
+// in line, then a conservative per-lane slab test against each box's inflated world box, culled against the hit it already
+// holds; a ray that may reach a box is appended to that box's list in LDS (wave-private; the entry carries the ray's slot and
+// the hit so far), and whenever a list holds 64 entries the wave tests THAT ONE box for 64 rays at once, every lane busy, the
+// object record still wave-uniform (scalar loads).  A ray listed for both boxes goes from the first list to the second.
+// The deferred objects are the LAST n_def of the scene and are run in index order with t_max = the hit so far, so every ray
+// sees exactly the sequence of exact tests of scene.rs:137-149 minus tests that cannot succeed: the bits do not change.
+// (Round 2's first attempt kept one list with a shape mask per ray and lost, 19.2 -> 24.4 ms: per-lane object records in
+// the run phase, 18 spills.  One list per object keeps the records scalar.)
+// Dynamic LDS per wave: list 0: DEFER0_CAP entries, list 1: DEFER1_CAP entries, 12 bytes each.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t DEFER0_CAP = 128, DEFER1_CAP = 192;     // between two runs list 0 grows by <= 64 (one chunk), list 1 by <= 64 (the chunk) + <= 64 (list 0's run)
+extern __shared__ uint32_t lds_defer[];
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_DEFER_WAVES, 8)))
+void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, uint32_t n_def) {
+    const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
+    if (w >= q.n_waves) return;
+    const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w], base = w * q.cap;
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    const uint32_t n_first = sc.n_objects - n_def;
+    uint32_t *l_slot[2] = {lds_defer, lds_defer + 3 * DEFER0_CAP};
+    uint32_t cap_[2] = {DEFER0_CAP, DEFER1_CAP};
+    // entry e of list d: [slot | later-list bit 31][t][code]
+    auto E = [&](uint32_t d, uint32_t e, uint32_t field) -> uint32_t & { return l_slot[d][field * cap_[d] + e]; };
+    uint32_t cnt0 = 0, cnt1 = 0;
+    const RngKey nokey{0, 0, 0};
+    auto write_final = [&](uint32_t slot, float t, uint32_t code) {
+        if (f.hit4) reinterpret_cast<uint32_t *>(hits)[slot] = code; else qst(&hits[slot], make_float2(t, __uint_as_float(code)));
+    };
+    auto append = [&](uint32_t d, bool want, uint32_t slot_bits, float t, uint32_t code) {
+        const unsigned long long m = __ballot(want);
+        if (!m) return;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        uint32_t &cnt = d == 0 ? cnt0 : cnt1;
+        if (want) { const uint32_t e = cnt + rank; E(d, e, 0) = slot_bits; E(d, e, 1) = __float_as_uint(t); E(d, e, 2) = code; }
+        cnt += (uint32_t)__popcll(m);
+    };
+    // The exact test of deferred object d for up to 64 listed rays (one per lane).  The rays are gathered again by slot
+    // (L2-warm).  (Requesting them one chunk ahead, across the in-line work, costs 12 registers: 80 with 8 spills, 18.6 vs
+    // 18.4 ms.)
+    auto run = [&](uint32_t d, uint32_t take) {
+        uint32_t &cnt = d == 0 ? cnt0 : cnt1;
+        const uint32_t e = cnt - take + lane;
+        const bool on = lane < take;
+        uint32_t sb = 0, code = MISS; float t = TMAX;
+        if (on) { sb = E(d, e, 0); t = __uint_as_float(E(d, e, 1)); code = E(d, e, 2); }
+        cnt -= take;
+        const uint32_t slot = sb & 0x7fffffffu;
+        if (on) {
+            const float4 ra = qld(&in.ray_a[slot]); const float2 rb = load_ray_b(in, slot, f, segment);
+            const Ray r = make_ray(ra, rb, f, segment);
+            const uint32_t k = n_first + d;
+            const Obj o = load_obj(sc.obj, k);                        // wave-uniform: scalar loads
+            float tt; uint32_t prim;
+            if (hit_object(sc, o, k, r, TMIN, t, nullptr, nokey, segment, tt, prim)) { t = tt; code = (k << sc.prim_bits) | prim; }
+        }
+        const bool more = on && (sb >> 31) != 0u;                      // only list 0 entries can carry it
+        if (d == 0) append(1, more, slot, t, code);
+        if (on && !more) write_final(slot, t, code);
+    };
+    float4 ra_n = make_float4(0, 0, 0, 0); float2 rb_n = make_float2(0, 0);
+    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); }
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const uint32_t j = c0 + lane, i = base + j;
+        const float4 ra = ra_n; const float2 rb = rb_n;
+        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); }
+        const bool active = j < n;
+        float best_t = TMAX; uint32_t best_obj = MISS, best_prim = 0;
+        bool may0 = false, may1 = false;
+        if (active) {
+            const Ray r = make_ray(ra, rb, f, segment);
+            const float4 *op = sc.obj;
+            for (uint32_t k = 0; k < n_first; k++, op += OBJ_Q) {
+                const Obj o = load_obj(op, 0);
+                float t; uint32_t prim;
+                if (hit_object(sc, o, k, r, TMIN, best_t, nullptr, nokey, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+            }
+            // conservative pre-tests (see closest_hit's segment-0 cull: approximate reciprocals, boxes inflated by 1e-4 of the
+            // scene and ray-origin scale, NaN-dropping min/max), here per lane and also culled against the hit so far
+            const V3 ainv = mk(__builtin_amdgcn_rcpf(r.d.x), __builtin_amdgcn_rcpf(r.d.y), __builtin_amdgcn_rcpf(r.d.z));
+            const float eps = 1e-4f * (fabsf(r.o.x) + fabsf(r.o.y) + fabsf(r.o.z));
+            for (uint32_t d = 0; d < n_def; d++) {
+                const uint32_t k = n_first + d;
+                const float4 lo = sc.obj_cull[2 * (size_t)k], hi = sc.obj_cull[2 * (size_t)k + 1];
+                const float m = eps + 1e-4f * (fmaxf(fmaxf(fabsf(lo.x), fabsf(lo.y)), fabsf(lo.z)) + fmaxf(fmaxf(fabsf(hi.x), fabsf(hi.y)), fabsf(hi.z))) + 1e-6f;
+                float t0 = (lo.x - m - r.o.x) * ainv.x, t1 = (hi.x + m - r.o.x) * ainv.x;
+                float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+                t0 = (lo.y - m - r.o.y) * ainv.y; t1 = (hi.y + m - r.o.y) * ainv.y;
+                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                t0 = (lo.z - m - r.o.z) * ainv.z; t1 = (hi.z + m - r.o.z) * ainv.z;
+                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                const bool maybe = !(tf < tn * (1.f - 1e-4f) - 1e-4f) && !(tf < 0.f) && !(tn * (1.f - 1e-4f) - 1e-4f > best_t);
+                if (d == 0) may0 = maybe; else may1 = maybe;
+            }
+        }
+        const uint32_t code = best_obj == MISS ? MISS : ((best_obj << sc.prim_bits) | best_prim);
+        append(0, may0, i | (may1 ? 0x80000000u : 0u), best_t, code);
+        append(1, may1 && !may0, i, best_t, code);
+        if (active && !may0 && !may1) write_final(i, best_t, code);
+        if (cnt0 >= 64u) run(0, 64u);                                 // <= 64 more entries for list 1
+        while (cnt1 >= 64u) run(1, 64u);
+    }
+    while (cnt0) run(0, min(cnt0, 64u));
+    while (cnt1) run(1, min(cnt1, 64u));
+}
+
+// (The first attempt of round 2 to DEFER the expensive shapes of the linear scan — k_extend_linear_defer above is the second: cornell's two rotated boxes are 12 of a ray's 18 rectangle
 // tests and 44 % of k_extend_linear (tools/cornell_parts.py), and a bounce ray can reach each only about one time in four.
 // The scan tested the cheap shapes in line, appended the rays whose inflated world-box test passed to a wave-private LDS
 // list with a bit mask of shapes, and ran the listed rays 64 at a time with every lane busy; equal t went to the later
@@ -2248,6 +2361,7 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
         else hipLaunchKernelGGL(k_extend_tlas, sg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     }
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+    else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)(DEFER0_CAP + DEFER1_CAP) * 12, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float2 *hits,

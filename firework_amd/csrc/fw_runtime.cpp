@@ -326,6 +326,7 @@ struct fw_scene {
     DevBuf data;   // every scene array in one allocation (sections 256-byte aligned)
     uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mat = 0, n_tex = 0;
     uint32_t blas_pair_nodes = 0, tlas_pair_nodes = 0, max_tris = 0, n_tris = 0;
+    uint32_t n_defer = 0;
     bool simple_shapes = false;   // every object is a sphere, an axis-aligned rect or a Rect3d (no medium, mesh, cone, cylinder, disk)
     bool hdr_env = false;
     ~fw_scene() {
@@ -740,6 +741,13 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     sc->hdr_env = e.kind == FW_ENV_HDR;
     sc->simple_shapes = true;
     for (uint32_t i = 0; i < desc->n_objects; i++) { uint32_t kf; std::memcpy(&kf, &objs[(size_t)i * fw::OBJ_Q * 4 + 3], 4); if ((kf & 0xffu) > 4u) sc->simple_shapes = false; }
+    // the trailing plain boxes of a linear scene (k_extend_linear_defer): at most two, no media or meshes anywhere in the scene
+    sc->n_defer = 0;
+    if (!has_medium && fl.tri.empty())
+        for (uint32_t i = desc->n_objects; i-- > 0 && sc->n_defer < 2u;) {
+            uint32_t kf; std::memcpy(&kf, &objs[(size_t)i * fw::OBJ_Q * 4 + 3], 4);
+            if ((kf & 0xffu) == (uint32_t)FW_SHAPE_RECT3D && (((kf >> 8) & 0xffffu) & fw::OF_CULL0) && !(((kf >> 8) & 0xffffu) & fw::OF_GATE)) sc->n_defer++; else break;
+        }
     sc->tlas_nodes = ref_tlas_nodes; sc->blas_nodes = fl.ref_blas_nodes;   // reported: the reference topology (bvh.rs)
     sc->tlas_depth = tlas_p.depth; sc->blas_depth = fl.blas_depth;
     sc->blas_pair_nodes = fl.blas.count(); sc->tlas_pair_nodes = tlas_p.count(); sc->max_tris = fl.max_tris; sc->n_tris = (uint32_t)(fl.tri.size() / 12);
@@ -896,6 +904,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.n_cus = sc->n_cus;
     cfg.blas_pair_nodes = sc->blas_pair_nodes; cfg.tlas_pair_nodes = sc->tlas_pair_nodes; cfg.max_tris = sc->max_tris; cfg.n_tris = sc->n_tris;
     cfg.no_lds_tris = getenv("FIREWORK_NO_LDS_TRIS") != nullptr;
+    cfg.n_defer = (!p->use_bvh && getenv("FIREWORK_NO_DEFER") == nullptr) ? sc->n_defer : 0u;
     cfg.lds_trees = getenv("FIREWORK_NO_LDS_TREES") == nullptr;
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);

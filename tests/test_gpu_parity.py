@@ -321,6 +321,45 @@ def test_deposit_bitmap_layouts_and_hit_record_sizes_are_bit_identical(monkeypat
         assert frames[3].stats["bytes_shade"] > frames[0].stats["bytes_shade"]      # 8-byte hit records
 
 
+def test_deferred_boxes_of_the_linear_scan_are_bit_identical(oracle, monkeypatch):
+    """k_extend_linear_defer takes the trailing Rect3d objects of a linear scene out of the per-ray loop (per-box lists in LDS,
+    64 rays per exact test).  Rooms with one, two and three trailing boxes — rotated, overlapping each other, standing on the
+    floor (equal-t ties with the floor rect), one flipped, glass and metal among them, a sphere in between — rendered with the
+    deferral, without it (FIREWORK_NO_DEFER) and by the oracle: same rays per depth, same bits between the two GPU paths."""
+    rng = np.random.default_rng(77)
+    u = lambda a, b: float(rng.uniform(a, b))
+    for n_boxes in (1, 2, 3):
+        sc = Scene.new()
+        white = sc.add_material(LambertianMat.with_color((0.73, 0.73, 0.73)))
+        red = sc.add_material(LambertianMat.with_color((0.65, 0.05, 0.05)))
+        light = sc.add_material(EmissiveMat.with_color((9.0, 9.0, 9.0)))
+        glass = sc.add_material(DielectricMat.new(1.5))
+        metal = sc.add_material(MetalMat.new((0.8, 0.8, 0.9), 0.1))
+        sc.add_object(RenderObject.new(XZRect.new(-4, 4, -4, 4, 0.0, white)))                    # floor
+        sc.add_object(RenderObject.new(XZRect.new(-4, 4, -4, 4, 5.0, white)).flip_normals())     # ceiling
+        sc.add_object(RenderObject.new(XZRect.new(-1, 1, -1, 1, 4.99, light)).flip_normals())
+        sc.add_object(RenderObject.new(XYRect.new(-4, 4, 0, 5, 4.0, red)).flip_normals())
+        sc.add_object(RenderObject.new(YZRect.new(0, 5, -4, 4, -4.0, white)))
+        sc.add_object(RenderObject.new(Sphere.new(0.7, glass)).position(-2.0, 0.7, 1.0))
+        mats = [white, metal, glass]
+        for b in range(n_boxes):
+            ro = RenderObject.new(Rect3d.with_size((u(1.0, 2.0), u(1.0, 3.0), u(1.0, 2.0)), mats[b % 3]))
+            ro = ro.rotate(Rotor3.from_rotation_xz(u(-1.0, 1.0)) if b != 1 else Rotor3.from_euler_angles(u(-0.4, 0.4), u(-0.4, 0.4), u(-0.4, 0.4)))
+            ro = ro.position(u(-1.5, 0.5), 0.0 if b != 1 else u(0.0, 0.8), u(-1.0, 1.0))         # boxes overlap; on the floor: ties
+            if b == 2:
+                ro = ro.flip_normals()
+            sc.add_object(ro)
+        cam = CameraSettings.default().cam_pos((0.5, 2.5, -11.0)).look_at((0.0, 2.2, 0.0)).field_of_view(38.0)
+        r = Renderer.default().width(72).height(56).samples(24).use_bvh(False).camera(cam).seed(5 + n_boxes)
+        monkeypatch.delenv("FIREWORK_NO_DEFER", raising=False)
+        gpu, cpu = check(oracle, sc, r)
+        monkeypatch.setenv("FIREWORK_NO_DEFER", "1")
+        plain = r.render_full(sc)
+        monkeypatch.delenv("FIREWORK_NO_DEFER", raising=False)
+        assert np.array_equal(gpu.linear, plain.linear) and gpu.stats["rays_per_depth"] == plain.stats["rays_per_depth"]
+        assert gpu.stats["rays_per_depth"] == cpu.stats["rays_per_depth"]
+
+
 def test_errors_cross_the_abi_as_codes():
     from firework_amd import _abi as A
     r = Renderer.default().width(8).height(8).samples(1)
