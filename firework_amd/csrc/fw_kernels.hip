@@ -1988,7 +1988,9 @@ extern __shared__ float4 lds_tables[];
 template <int LDS_TAB>   // 1: object + material + texture tables staged in LDS; 2: materials + textures only (part2: 1 409 objects are 135 KB, its 10 materials are not); 0: none
 // 5 waves per SIMD (96 VGPRs, no spills) instead of the compiler's 4 (114): nothing while the scattered zero deposits bound
 // the kernel (round 1), now cornell k_shade 20.55 -> 20.13 ms (four interleaved pairs), hdri 5.84 -> 5.56, suzanne 4.74 -> 4.57;
-// 6 waves (80 VGPRs) spill three registers and gain nothing more.
+// 6 waves (80 VGPRs) spill three registers and gain nothing more.  Requesting the queue entries TWO chunks ahead (11 more
+// registers; at 4 or at 5 waves) changes nothing that four interleaved runs can resolve (the kernel's own run-to-run spread
+// is +-1 ms), nor does capping random_in_unit_sphere at one attempt: neither the prefetch distance nor that loop bounds it.
 #ifndef FW_SHADE_WAVES
 #define FW_SHADE_WAVES 5
 #endif
