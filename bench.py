@@ -232,7 +232,8 @@ def roofline_objects(acc, args, tr, renderer):
     n_sh = max(1, acc["n_shade_launches"] // steps)
     n_ex = max(1, acc["n_extend_launches"] // steps)
     sha = kernel_source_sha()
-    traffic = traffic_src = frac_traffic = None
+    traffic = traffic_src = frac_traffic = other_traffic = None
+    single_extend_kernel = False
     other_bound = other_src = None
     workload = f"{args.config} {renderer.settings['width']}x{renderer.settings['height']} @{renderer.settings['samples']}spp"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
@@ -242,6 +243,9 @@ def roofline_objects(acc, args, tr, renderer):
                 continue
             k = [k for k in d["kernels"] if "k_shade" in k][0]
             traffic, traffic_src = d["kernels"][k]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+            ke = max((k for k in d["kernels"] if "k_extend" in k or "k_blas" in k), key=lambda k: d["kernels"][k]["us_total_in_these_passes"])
+            other_traffic = d["kernels"][ke]["hbm_bytes_per_launch"]
+            single_extend_kernel = sum(1 for k in d["kernels"] if "k_extend" in k or "k_blas" in k) == 1
             break
         except Exception:
             continue
@@ -268,7 +272,9 @@ def roofline_objects(acc, args, tr, renderer):
         "other_kernel": {"kernel": "k_extend", "bound": other_bound, "bound_source": other_src,
                          "ms_per_step": ext_s * 1e3, "achieved": ext_bytes / ext_s / 1e9 if ext_s > 0 else 0.0,
                          "frac_hbm": ext_bytes / ext_s / 1e9 / HBM_PEAK_GBS if ext_s > 0 else 0.0,
-                         "algorithmic_bytes_per_launch": ext_bytes / n_ex, "avg_launch_us": ext_s * 1e6 / n_ex},
+                         "algorithmic_bytes_per_launch": ext_bytes / n_ex, "avg_launch_us": ext_s * 1e6 / n_ex,
+                         "traffic": other_traffic,     # PMC bytes per launch of the longest extend-class kernel (same source as above)
+                         "traffic_over_algorithmic": other_traffic / (ext_bytes / n_ex) if other_traffic and single_extend_kernel else None},
     }
     dev_s = acc["ms_render"] / 1e3 / steps
     layout = float(exact["bytes_raygen"] + exact["bytes_extend"] + exact["bytes_shade"] + exact["bytes_accumulate"])
