@@ -239,8 +239,8 @@ def roofline_objects(acc, args, tr, renderer):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
         try:
             d = json.load(open(path))
-            if d.get("source_sha") != sha or d.get("workload") != workload:
-                continue
+            if d.get("source_sha") != sha or d.get("workload") != workload or tr.world != 1:
+                continue                                  # the profiles are whole-frame runs: a rank's share moves 1/N of those bytes per launch
             k = [k for k in d["kernels"] if "k_shade" in k][0]
             traffic, traffic_src = d["kernels"][k]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
             ke = max((k for k in d["kernels"] if "k_extend" in k or "k_blas" in k), key=lambda k: d["kernels"][k]["us_total_in_these_passes"])
