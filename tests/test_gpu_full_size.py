@@ -139,14 +139,16 @@ def _bench(args, timeout=600):
 SMALL = ["--width", "128", "--height", "96", "--spp", "16", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-one-shot"]
 
 
-def test_eight_way_tiled_cornell_frame_equals_the_one_device_frame():
-    """The shares of an 8-rank cornell frame (32 Ki pixels each: pixel-major deposit bitmap, box lists, 4-byte hits) through
-    fw_render_scene_tiled with device 0 listed eight times: the assembled 512x512 frame and its counters equal one render's."""
-    s, r = scenes.config("C2_cornell_box", samples=24)
-    one = r.render_full(s)
-    tiled = _lib.render_scene_tiled(s.to_desc(), r, [0] * 8)
-    assert np.array_equal(one.linear, tiled.linear) and np.array_equal(one.rgb8, tiled.rgb8)
-    assert one.stats["rays_per_depth"] == tiled.stats["rays_per_depth"] and one.stats["samples"] == tiled.stats["samples"]
+def test_eight_way_tiled_frames_equal_the_one_device_frames():
+    """The shares of an 8-rank cornell frame (32 Ki pixels each: pixel-major deposit bitmap, box lists, 4-byte hits) and of an
+    8-rank part2 frame through fw_render_scene_tiled with device 0 listed eight times: the assembled full-size frames and
+    their counters equal one render's."""
+    for name, spp in (("C2_cornell_box", 24), ("C5_part2_all", 2)):      # C5: BASELINE's "tiled across 8", 1920x1080, TLAS in LDS
+        s, r = scenes.config(name, samples=spp)
+        one = r.render_full(s)
+        tiled = _lib.render_scene_tiled(s.to_desc(), r, [0] * 8)
+        assert np.array_equal(one.linear, tiled.linear) and np.array_equal(one.rgb8, tiled.rgb8), name
+        assert one.stats["rays_per_depth"] == tiled.stats["rays_per_depth"] and one.stats["samples"] == tiled.stats["samples"], name
 
 
 def test_bench_launches_its_own_ranks_and_the_frame_does_not_depend_on_them(tmp_path):
