@@ -5,12 +5,16 @@ committed under profiles/:
   <tag>_kernel_stats.csv  copy of rocprofv3 --kernel-trace --stats
   <tag>_pmc.json          per-kernel HBM bytes from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes
   <tag>_sq.json           per-kernel SQ summary (wave-time split, VALU busy fraction, lane utilisation, instruction mix)
-                          and the `bound` bench.py reports for the kernel:
-                            hbm         HBM traffic >= 45 % of 8 TB/s
-                            valu_issue  the VALU pipes execute >= 50 % of what they can (one wave64 instruction per 2 cycles
-                                        per SIMD-32, at the 2.4 GHz peak clock: a lower bound), or the waves spend >= 25 % of
-                                        their time ready but not issued (SQ_WAIT_INST_ANY)
-                            latency     neither: waves parked in s_waitcnt behind dependent loads
+                          and the `bound` bench.py reports for the kernel — the larger of two utilisations, each relative
+                          to what this chip was MEASURED to sustain, when it is >= 0.7:
+                            hbm         PMC bytes / time over 6.0 TB/s (= 0.75 of the 8 TB/s peak: what a kernel that only
+                                        copies wave-private queues reaches — tools/membench.hip, and k_shade with its shading
+                                        replaced by a move)
+                            valu_issue  SQ_INSTS_VALU x 3.7 cycles over the SIMD cycles of the launch (tools/issuebench.hip,
+                                        eight waves resident: v_fmac 3.0-3.6, min/cmp/cndmask/div_fixup 4.5, v_mad_u64_u32 5.1
+                                        cycles per wave64 instruction at the nominal 2.4 GHz; 3.7 is what the rectangle scan
+                                        runs at).  `valu_pipe_util` is the same count at the guide's 2 cycles per instruction
+                            latency     neither reaches 0.7: waves parked in s_waitcnt behind dependent loads
 
 usage: scripts/summarize_prof.py <dir> <tag> "<workload string of bench.py's config.workload>"
 
@@ -122,8 +126,10 @@ def main():
                "l2_hit_rate": round(v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"]), 3) if v.get("TCC_HIT_sum") else None}
         hb = pmc["kernels"].get(k, {}).get("hbm_GBps")
         row["hbm_frac_of_8TBps"] = round(hb * 1e9 / HBM_PEAK, 3) if hb else None
-        vb, stall = row["valu_pipe_util"] or 0.0, row["wave_time_split"]["issue_stall"] or 0.0
-        row["bound"] = "hbm" if (row["hbm_frac_of_8TBps"] or 0) >= 0.45 else ("valu_issue" if (vb >= 0.5 or stall >= 0.25) else "latency")
+        row["valu_issue_util"] = round(v.get("SQ_INSTS_VALU", 0) * 3.7 / simd_cycles, 3) if us else None      # at the measured 3.7 cycles per instruction
+        row["hbm_util_of_streaming"] = round((row["hbm_frac_of_8TBps"] or 0.0) / 0.75, 3)
+        vu, hu = row["valu_issue_util"] or 0.0, row["hbm_util_of_streaming"]
+        row["bound"] = "latency" if max(vu, hu) < 0.7 else ("hbm" if hu >= vu else "valu_issue")
         sq["kernels"][k] = row
     if sq["kernels"]:
         json.dump(sq, open(f"{ROOT}/profiles/{tag}_sq.json", "w"), indent=1)
