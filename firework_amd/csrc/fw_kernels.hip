@@ -264,9 +264,20 @@ __device__ __forceinline__ Ray camera_ray(const DCamera &cam, const DFrame &f, c
     uint4 j = draw(k, P_JITTER, 0, 0);
     float u = fdiv((float)px + u2f(j.x), rw);                         // render.rs:178
     float v = fdiv((float)py + u2f(j.y), rh);                         // render.rs:179
-    // camera.rs:109-116 — the disk sample is drawn even when the aperture is 0
+    V3 pos = ld3(cam.position);
+    if (cam.lens_radius == 0.f) {
+        // camera.rs:109-116 draws the disk sample even when the aperture is 0; then rd = 0 * sample = (+-0, +-0) and so is
+        // `offset`.  x + (+-0) = x and x - (+-0) = x for every x except -0, so unless a component of the position or of the
+        // direction-before-offset is a negative zero, the sample's signs cannot reach the ray: skip its rejection loop (half of
+        // k_raygen's instructions for a pinhole camera).  A lane that does meet a -0 takes the full expression below.
+        const V3 dd = ld3(cam.lower_left) + u * ld3(cam.horizontal) + v * ld3(cam.vertical) - pos;
+        const uint32_t NZ = 0x80000000u;
+        const bool neg0 = __float_as_uint(dd.x) == NZ || __float_as_uint(dd.y) == NZ || __float_as_uint(dd.z) == NZ ||
+                          __float_as_uint(pos.x) == NZ || __float_as_uint(pos.y) == NZ || __float_as_uint(pos.z) == NZ;
+        if (!neg0) return Ray{pos, dd};
+    }
     V3 rd = cam.lens_radius * random_in_unit_disk(k);
-    V3 cu = ld3(cam.u), cv = ld3(cam.v), pos = ld3(cam.position);
+    V3 cu = ld3(cam.u), cv = ld3(cam.v);
     V3 offset = cu * rd.x + cv * rd.y;
     V3 o = pos + offset;
     V3 d = ld3(cam.lower_left) + u * ld3(cam.horizontal) + v * ld3(cam.vertical) - pos - offset;
