@@ -355,7 +355,8 @@ def parity(args, tr, renderer, scene, frame_u8, cpu, cores):
             "rays_equal": bool(g.stats["rays"] == c.stats["rays"]), "rays_gpu": int(g.stats["rays"]), "rays_oracle": int(c.stats["rays"]),
             "timed_frame_equals_checked_frame": bool(np.array_equal(frame_u8[ids], g.rgb8)),
             "pixels": int(ids.shape[0]), "pixel_stride": stride, "spp": spp, "oracle_seconds": round(dt, 1),
-            "what": f"{args.config} {w}x{h} @{spp}spp, every {stride}th pixel in x and y, GPU vs CPU oracle (FW_RNG_CTR, same seed)"}
+            "what": f"{args.config} {w}x{h} @{spp}spp, " + ("every pixel" if stride == 1 else f"every {stride}{'nd' if stride == 2 else 'rd' if stride == 3 else 'th'} pixel in x and y")
+                    + ", GPU vs CPU oracle (FW_RNG_CTR, same seed)"}
 
 
 if __name__ == "__main__":
