@@ -47,8 +47,8 @@ def kernel_source_sha():
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="C2_cornell_box")
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
