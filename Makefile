@@ -7,7 +7,7 @@ ARCH ?= gfx950
 # (tools/microbench.hip), so SLP-packed pairs gain nothing and their repacking v_movs cost: k_extend<false> 25.1 -> 20.3 ms.
 HIPFLAGS ?= -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=$(ARCH) -Wall -Wno-unused-function
 SRC = firework_amd/csrc/fw_kernels.hip firework_amd/csrc/fw_runtime.cpp
-HDR = firework_amd/csrc/fw_device.h include/firework_hip.h Makefile
+HDR = firework_amd/csrc/fw_device.h firework_amd/csrc/fw_libm.h include/firework_hip.h Makefile
 LIB = firework_amd/lib/libfirework_hip.so
 
 all: $(LIB) oracle examples

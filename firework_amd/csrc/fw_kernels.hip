@@ -24,6 +24,7 @@
 // association as the reference's expressions, so hit/miss decisions follow the CPU oracle bit for
 // bit; only libm-class functions (sin, atan2, asin, log10, pow) differ by ulps.
 #include "fw_device.h"
+#include "fw_libm.h"
 #include <atomic>
 
 namespace fw {
@@ -402,8 +403,14 @@ __device__ __forceinline__ bool hit_rect(float a_min, float a_max, float b_min, 
         float slack = fminf(fminf(fminf(t - tmin, tmax - t), fminf(pa - a_min, a_max - pa)), fminf(pb - b_min, b_max - pb));
         return !(slack < 0.f);
     }
-    const float mt = __builtin_amdgcn_fmed3f(t, tmin, tmax), ma = __builtin_amdgcn_fmed3f(pa, a_min, a_max), mb = __builtin_amdgcn_fmed3f(pb, b_min, b_max);
-    return !(t < mt || t > mt) && !(pa < ma || pa > ma) && !(pb < mb || pb > mb);
+    // The t interval keeps its two literal comparisons: its upper bound is the closest hit so far, and that can be a NaN.  A ray
+    // that lies exactly in a rectangle's plane gives t = 0/0, which rect.rs:47-62 ACCEPTS (`t < t_min || t > t_max` is false for
+    // a NaN) — after which `closest` is NaN and every later, ordinary hit is accepted too, because `t > NaN` is false as well.
+    // v_med3 with a NaN operand returns min3 instead, i.e. it rejects them (and lets t < t_min through).  This was the one
+    // diverging path of cornell 512x512 @1024 (tools/diverge.py: pixel 112819, sample 170, segment 8: a bounce ray with
+    // d.y = 0 starting on the ceiling; the reference goes on to hit the back wall).  Position intervals have constant bounds.
+    const float ma = __builtin_amdgcn_fmed3f(pa, a_min, a_max), mb = __builtin_amdgcn_fmed3f(pb, b_min, b_max);
+    return !(t < tmin || t > tmax) && !(pa < ma || pa > ma) && !(pb < mb || pb > mb);
 }
 template <bool DEGENERATE>
 __device__ __forceinline__ bool hit_rect_kind_t(uint32_t kind, float4 q3, float k, const Ray &r, float tmin, float tmax, float &t) {
@@ -621,7 +628,11 @@ __device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, 
     return next;
 }
 // best t -> culling bound, a little beyond it whatever its sign (a medium's inner mesh is walked with t in (-MAX, MAX))
+#ifdef FW_NO_CULL     // A/B build (tools/diverge.py): no culling against the best hit, every box test is the reference's alone
+__device__ __forceinline__ float cull_bound(float) { return 3.40282347e+38f; }
+#else
 __device__ __forceinline__ float cull_bound(float t) { return t + fabsf(t) * 1e-6f; }
+#endif
 
 // K4  mesh BLAS (bvh.rs:100-151 over Triangle items).  The reference visits BOTH children with the caller's
 // [tmin,tmax] and keeps the smaller t, the right/later item winning ties.  Here: front-to-back traversal
@@ -692,17 +703,20 @@ __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const
     float dmag = mag(r.d);
     float dist_inside_boundary = (t2 - t1) * dmag;
     float xi = u2f(draw(key, P_VOLUME, segment, obj_index).x);
-    float hit_distance = -fdiv(1.f, o.q4.w) * log10f(xi);       // log10, as written (volume.rs:67)
+    float hit_distance = -fdiv(1.f, o.q4.w) * fwlm::log10f_glibc(xi);       // log10, as written (volume.rs:67); glibc's bits (fw_libm.h)
     if (hit_distance < dist_inside_boundary) { t_out = t1 + fdiv(hit_distance, dmag); return true; }
     return false;
 }
 
 // RenderObjectInternal::hit up to the object-space t (the world-space point/normal are rebuilt in k_shade)
+// MEDIUM = false: the caller's scene holds no ConstantMedium (k_extend_linear_defer: the host checks), so the medium's code —
+// its double-precision log10 costs registers even where it never runs — is compiled out
+template <bool MEDIUM = true>
 __device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint32_t obj_index, const Ray &world, float tmin,
                                            float tmax, uint32_t *stack_base, const RngKey &key, uint32_t segment, float &t, uint32_t &prim) {
     Ray r = to_object_space(o, world);
     uint32_t kind = obj_kind(o);
-    if (kind == 6) { prim = 0; return hit_medium(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
+    if (MEDIUM && kind == 6) { prim = 0; return hit_medium(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
     return hit_shape(sc, kind, o.q3, o.q4, o.aux0, o.aux1, r, tmin, tmax, stack_base, t, prim);
 }
 
@@ -1277,7 +1291,7 @@ void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ 
             const uint32_t k = n_first + d;
             const Obj o = load_obj(sc.obj, k);                        // wave-uniform: scalar loads
             float tt; uint32_t prim;
-            if (hit_object(sc, o, k, r, TMIN, t, nullptr, nokey, segment, tt, prim)) { t = tt; code = (k << sc.prim_bits) | prim; }
+            if (hit_object<false>(sc, o, k, r, TMIN, t, nullptr, nokey, segment, tt, prim)) { t = tt; code = (k << sc.prim_bits) | prim; }
         }
         const bool more = on && (sb >> 31) != 0u;                      // only list 0 entries can carry it
         if (d == 0) append(1, more, slot, t, code);
@@ -1298,7 +1312,7 @@ void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ 
             for (uint32_t k = 0; k < n_first; k++, op += OBJ_Q) {
                 const Obj o = load_obj(op, 0);
                 float t; uint32_t prim;
-                if (hit_object(sc, o, k, r, TMIN, best_t, nullptr, nokey, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+                if (hit_object<false>(sc, o, k, r, TMIN, best_t, nullptr, nokey, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
             }
             // conservative pre-tests (see closest_hit's segment-0 cull: approximate reciprocals, boxes inflated by 1e-4 of the
             // scene and ray-origin scale, NaN-dropping min/max), here per lane and also culled against the hit so far
@@ -1984,8 +1998,12 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
     // every path deposits exactly once — except zeros over a black environment: k_raygen has already written them, densely
     // (adding +0 is exact, and most indoor paths end black; the scattered 16-byte deposits are k_shade's costliest stores)
     if (!alive && !(f.skip_zero_deposits && rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
-        if (FW_NT_RAD) st_nt(&sample_rad[path_id], make_float4(rad.x, rad.y, rad.z, 0.f));
-        else sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, 0.f);
+        // .w = the path's length in segments: k_accumulate sums it next to the colour, so accum.w of a pixel is its ray count
+        // whenever every path deposits (any non-black environment, or FIREWORK_NO_ZERO_SKIP=1) — what tools/diverge.py
+        // compares with the oracle's per-pixel counts to find a diverging path
+        const float len = (float)(segment + 1);
+        if (FW_NT_RAD) st_nt(&sample_rad[path_id], make_float4(rad.x, rad.y, rad.z, len));
+        else sample_rad[path_id] = make_float4(rad.x, rad.y, rad.z, len);
         if (f.skip_zero_deposits) {                                  // "this path wrote a record" (3.6 % of cornell's paths)
             const uint32_t b = f.dep_pixel_major ? dep_bit_of(f, path_id) : path_id;
             atomicOr(&f.dep_bits[b >> 5], 1u << (b & 31u));
@@ -2174,11 +2192,11 @@ __global__ __launch_bounds__(WB) void k_accumulate(DFrame f, const float4 *__res
 #pragma unroll
                     for (int k = 0; k < 16; k++) { h[k] = home_then_advance(); bw[k] = f.dep_bits[h[k] >> 5]; }
 #pragma unroll
-                    for (int k = 0; k < 16; k++) if ((bw[k] >> (h[k] & 31u)) & 1u) { const float4 v = sample_rad[h[k]]; a.x += v.x; a.y += v.y; a.z += v.z; }
+                    for (int k = 0; k < 16; k++) if ((bw[k] >> (h[k] & 31u)) & 1u) { const float4 v = sample_rad[h[k]]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
                 }
                 for (; s < f.spp_batch; s++) {
                     const uint32_t h = home_then_advance();
-                    if ((f.dep_bits[h >> 5] >> (h & 31u)) & 1u) { const float4 v = sample_rad[h]; a.x += v.x; a.y += v.y; a.z += v.z; }
+                    if ((f.dep_bits[h >> 5] >> (h & 31u)) & 1u) { const float4 v = sample_rad[h]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
                 }
                 accum[p] = a;
                 continue;
@@ -2202,7 +2220,7 @@ __global__ __launch_bounds__(WB) void k_accumulate(DFrame f, const float4 *__res
                         const uint32_t lin = (j * 32u + bit - b0) * f.n_pixels + p;       // s_local * n_pixels + p
                         const uint32_t g = lin >> 6, cc = g / f.q_n_waves, ww = g - cc * f.q_n_waves;
                         const float4 v = sample_rad[(ww << (f.q_shift + 6u)) | (cc << 6) | (lin & 63u)];
-                        a.x += v.x; a.y += v.y; a.z += v.z;
+                        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
                     }
                 }
             }
@@ -2214,11 +2232,11 @@ __global__ __launch_bounds__(WB) void k_accumulate(DFrame f, const float4 *__res
 #pragma unroll
             for (int k = 0; k < 16; k++) v[k] = sample_rad[home_then_advance()];
 #pragma unroll
-            for (int k = 0; k < 16; k++) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; }   // render.rs:181: total_color += color(...)
+            for (int k = 0; k < 16; k++) { a.x += v[k].x; a.y += v[k].y; a.z += v[k].z; a.w += v[k].w; }   // render.rs:181: total_color += color(...)
         }
         for (; s < f.spp_batch; s++) {
             float4 v = sample_rad[home_then_advance()];
-            a.x += v.x; a.y += v.y; a.z += v.z;
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         accum[p] = a;
     }

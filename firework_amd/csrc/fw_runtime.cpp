@@ -942,6 +942,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     const char *fe = getenv("FIREWORK_FUSED");
     const bool fused = fe && atoi(fe) != 0 && !(use_bvh && cfg.has_mesh);
 
+    // FIREWORK_DUMP_PATH=file, one pixel x one sample: after every k_extend the path's ray, state and hit record are copied out
+    // and written to `file` as 11 x 16 floats (ray_a[4] ray_b[2] state[4] hit[2] alive pad[3]) behind a header of 8 u32
+    // (magic, pinhole0, hit4, prim_bits, bits of cam_pos[3], n_defer).  Debug aid of tools/diverge.py; never on a timed path.
+    const char *dump_file = getenv("FIREWORK_DUMP_PATH");
+    const bool dump_one = dump_file && *dump_file && n_pix == 1 && p->samples == 1 && !fused;
+    std::vector<float> dump_rec(dump_one ? (size_t)fw::MAX_SEGMENTS * 16 : 0, 0.f);
+
     HIPCHK(hipEventRecord(ws->events[0], stream));
     if (n_lanes > 1) {     // fork: the lane streams start after everything queued on the caller's stream so far
         HIPCHK(hipEventRecord(ws->events[2], stream));
@@ -977,6 +984,17 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
             else {
                 timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park); });
+                if (dump_one) {     // debug (tools/diverge.py): the one path of this call sits in slot 0 of wave 0 in every segment
+                    float *r = &dump_rec[(size_t)seg * 16];
+                    uint32_t alive = 0;
+                    HIPCHK(hipMemcpyAsync(&alive, cfg.q.wcount + (size_t)seg * q.n_waves, 4, hipMemcpyDeviceToHost, ls));
+                    HIPCHK(hipMemcpyAsync(r, buf[cur].ray_a, 16, hipMemcpyDeviceToHost, ls));
+                    HIPCHK(hipMemcpyAsync(r + 4, buf[cur].ray_b, 8, hipMemcpyDeviceToHost, ls));
+                    HIPCHK(hipMemcpyAsync(r + 6, buf[cur].state, 16, hipMemcpyDeviceToHost, ls));
+                    HIPCHK(hipMemcpyAsync(r + 10, hits, 8, hipMemcpyDeviceToHost, ls));
+                    HIPCHK(hipStreamSynchronize(ls));
+                    r[12] = (float)alive;
+                }
                 timed(2, [&] { fw::launch_shade(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], hits, srad, seg); });
             }
             cur ^= 1;
@@ -996,6 +1014,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     HIPCHK(hipEventRecord(ws->events[1], stream));
     HIPCHK(hipGetLastError());
 
+    if (dump_one) {
+        if (FILE *fp = fopen(dump_file, "wb")) {
+            uint32_t hdr[8] = {0x46574450u, fr.pinhole0, fr.hit4, sc->d.prim_bits, 0, 0, 0, cfg.n_defer};
+            std::memcpy(&hdr[4], fr.cam_pos, 12);
+            fwrite(hdr, 4, 8, fp); fwrite(dump_rec.data(), 4, dump_rec.size(), fp); fclose(fp);
+        }
+    }
     const bool trace = getenv("FIREWORK_TRACE") != nullptr;
     const auto tq0 = std::chrono::steady_clock::now();
     auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };

@@ -146,15 +146,18 @@ def hdri_test(hdr=None):
     return scene, renderer
 
 
-def volume_test():
-    """examples/volume_test.rs:11-67"""
+def volume_test(medium_radius=1.0, glass_radius=1.01, density=0.5, with_glass=True):
+    """examples/volume_test.rs:11-67.  The defaults are the example as committed.  The reference's volume.png was rendered
+    when the two radii were 1.5 and 1.51 (everything else as today: tests/test_reference_renders.py fits the silhouette and
+    the inner circle of the glass sphere seen through the medium) — `volume_test(1.5, 1.51)` is that scene."""
     scene = Scene.new()
     glass = scene.add_material(DielectricMat.new(1.5))
     diffuse = scene.add_material(LambertianMat.with_color((0.8, 0.8, 0.8)))
     scene.add_material(MetalMat.new((0.7, 0.7, 0.7), 0.0))   # `metal` is added but unused in the example
-    scene.add_volume(RenderObject.new(Sphere.new(1.0, diffuse)).position(0.0, 1.0, 0.0), 0.5,
+    scene.add_volume(RenderObject.new(Sphere.new(medium_radius, diffuse)).position(0.0, 1.0, 0.0), density,
                      ConstantTexture.from_rgb(0.5, 0.0, 0.8))
-    scene.add_object(RenderObject.new(Sphere.new(1.01, glass)).position(0.0, 1.0, 1.0))
+    if with_glass:
+        scene.add_object(RenderObject.new(Sphere.new(glass_radius, glass)).position(0.0, 1.0, 1.0))
     scene.add_object(RenderObject.new(XZRect.new(-100.0, 100.0, -100.0, 100.0, 0.0, diffuse)))
     light = scene.add_material(EmissiveMat.with_color((8.0, 8.0, 8.0)))
     scene.add_object(RenderObject.new(YZRect.new(0.0, 20.0, 0.0, 10.0, -3.0, light))

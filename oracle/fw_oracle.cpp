@@ -922,12 +922,25 @@ struct Camera {
     }
 };
 
+// Debug probe (fwo_trace_path, tools/diverge.py): when set, color() records every segment of the path it follows —
+// 16 floats per depth: ray o, d | hit flag, t, material | point | normal | pad.
+thread_local float *g_path_trace = nullptr;
+
 // render.rs:12-33
 V3 color(const Ray &r, const SceneInternal &scene, const Hitable &root, size_t depth, Rng &rng, uint64_t *rays_per_depth) {
     rng.segment = (uint32_t)depth;
     rays_per_depth[depth]++;
     Hit hit;
-    if (root.hit(r, 0.001f, 2e9f, rng, hit)) {
+    const bool was_hit = root.hit(r, 0.001f, 2e9f, rng, hit);
+    if (g_path_trace) {
+        float *o = g_path_trace + 16 * depth;
+        o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+        o[6] = was_hit ? 1.f : 0.f;
+        if (was_hit) { o[7] = hit.t; o[8] = (float)hit.material; o[9] = hit.point.x; o[10] = hit.point.y; o[11] = hit.point.z;
+                       o[12] = hit.normal.x; o[13] = hit.normal.y; o[14] = hit.normal.z; }
+        o[15] = 1.f;     // this depth was reached
+    }
+    if (was_hit) {
         const Material &m = *scene.materials[hit.material];
         V3 emit = m.emit(hit.u, hit.v, hit.point);
         if (depth < 10) {
@@ -1044,6 +1057,93 @@ int fwo_render(const fw_scene_desc *desc, const fw_render_params *params, int n_
         stats->tlas_nodes = tl.nodes; stats->blas_nodes = scene.blas_nodes;
         stats->reserved = (uint32_t)n_threads;
     }
+    return FW_OK;
+}
+
+// ---- divergence probes (tools/diverge.py, tests/test_gpu_divergence.py) ------------------------------------------
+// Shared set-up of the three probes below.
+namespace {
+struct ProbeCtx {
+    SceneInternal scene; std::unique_ptr<BVHNode<ObjRef>> bvh; BvhStats tl; int status = FW_OK;
+    ProbeCtx(const fw_scene_desc *desc, const fw_render_params *params) {
+        if (!desc || !params || params->width == 0 || params->height == 0) { status = FW_ERR_BAD_ARG; return; }
+        try {
+            build_scene(desc, scene);
+            if (params->use_bvh) {
+                const SceneInternal *sp = &scene;
+                bvh = build_bvh<ObjRef>([sp](size_t i) { return ObjRef{sp->render_objects[i].get()}; }, scene.render_objects.size(), tl);
+            }
+        } catch (BuildError &e) { status = e.status; } catch (NanBBox &) { status = FW_ERR_NAN_BBOX; } catch (std::bad_alloc &) { status = FW_ERR_OOM; }
+    }
+    const Hitable &root(const fw_render_params *params) const { return params->use_bvh ? static_cast<const Hitable &>(*bvh) : static_cast<const Hitable &>(scene); }
+};
+// one camera sample of render_pixel (render.rs:177-181): returns the colour, counts its segments in rpd
+V3 one_sample(const fw_render_params &p, const SceneInternal &scene, const Hitable &root, const Camera &cam, size_t idx, uint32_t s, uint64_t *rpd) {
+    Rng rng;
+    rng.mode = FW_RNG_CTR; rng.seed32 = fold_seed(p.seed); rng.pixel = (uint32_t)idx; rng.sample = s; rng.segment = 0;
+    size_t px = idx % p.width, py = p.height - (idx / p.width);
+    float j[2];
+    rng.draw(P_JITTER, 0, 2, j);
+    float u = ((float)px + j[0]) / (float)p.width;
+    float v = ((float)py + j[1]) / (float)p.height;
+    Ray ray = cam.ray(u, v, rng);
+    return color(ray, scene, root, 0, rng, rpd);
+}
+}
+// Per-pixel ray counts of a CTR render (samples [0, params->samples)): rays_per_pixel[i] for the i-th pixel (pixel_ids order).
+int fwo_render_counts(const fw_scene_desc *desc, const fw_render_params *params, int n_threads, uint32_t *rays_per_pixel) {
+    if (!rays_per_pixel || !params || params->samples == 0) return FW_ERR_BAD_ARG;
+    ProbeCtx cx(desc, params);
+    if (cx.status) return cx.status;
+    Camera cam(params->camera, params->width, params->height);
+    const Hitable &root = cx.root(params);
+    size_t npix = params->pixel_ids ? params->n_pixels : (size_t)params->width * params->height;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            size_t b = next.fetch_add(64);
+            if (b >= npix) break;
+            for (size_t i = b; i < std::min(npix, b + 64); i++) {
+                size_t idx = params->pixel_ids ? params->pixel_ids[i] : i;
+                uint64_t rpd[FW_MAX_SEGMENTS + 1] = {0};
+                for (uint32_t s = 0; s < params->samples; s++) one_sample(*params, cx.scene, root, cam, idx, s, rpd);
+                uint64_t n = 0; for (int d = 0; d < FW_MAX_SEGMENTS; d++) n += rpd[d];
+                rays_per_pixel[i] = (uint32_t)n;
+            }
+        }
+    };
+    std::vector<std::thread> th; for (int t = 0; t < n_threads; t++) th.emplace_back(worker); for (auto &t : th) t.join();
+    return FW_OK;
+}
+// Path length (segments, 1..11) of each sample first_sample .. first_sample + n - 1 of one pixel.
+int fwo_path_lengths(const fw_scene_desc *desc, const fw_render_params *params, uint32_t pixel, uint32_t first_sample, uint32_t n, uint8_t *out) {
+    if (!out) return FW_ERR_BAD_ARG;
+    ProbeCtx cx(desc, params);
+    if (cx.status) return cx.status;
+    Camera cam(params->camera, params->width, params->height);
+    const Hitable &root = cx.root(params);
+    for (uint32_t k = 0; k < n; k++) {
+        uint64_t rpd[FW_MAX_SEGMENTS + 1] = {0};
+        one_sample(*params, cx.scene, root, cam, pixel, first_sample + k, rpd);
+        uint64_t len = 0; for (int d = 0; d < FW_MAX_SEGMENTS; d++) len += rpd[d];
+        out[k] = (uint8_t)len;
+    }
+    return FW_OK;
+}
+// Every segment of the path of (pixel, sample): out = 11 x 16 floats (see g_path_trace), colour = its radiance.
+int fwo_trace_path(const fw_scene_desc *desc, const fw_render_params *params, uint32_t pixel, uint32_t sample, float *out, float colour[3]) {
+    if (!out) return FW_ERR_BAD_ARG;
+    ProbeCtx cx(desc, params);
+    if (cx.status) return cx.status;
+    Camera cam(params->camera, params->width, params->height);
+    std::memset(out, 0, sizeof(float) * 16 * FW_MAX_SEGMENTS);
+    uint64_t rpd[FW_MAX_SEGMENTS + 1] = {0};
+    g_path_trace = out;
+    V3 c = one_sample(*params, cx.scene, cx.root(params), cam, pixel, sample, rpd);
+    g_path_trace = nullptr;
+    if (colour) { colour[0] = c.x; colour[1] = c.y; colour[2] = c.z; }
     return FW_OK;
 }
 

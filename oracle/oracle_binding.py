@@ -225,3 +225,46 @@ def trace(scene, rays, use_bvh=False, seed=0):
     if rc:
         raise OracleError(rc)
     return out
+
+
+# ---- divergence probes (tools/diverge.py, tests/test_gpu_divergence.py) ----------------------------------------------
+def _params(scene, renderer, pixel_ids=None):
+    from firework_amd.api import SceneDesc
+    sd = scene if isinstance(scene, SceneDesc) else scene.to_desc()
+    ids = None if pixel_ids is None else np.ascontiguousarray(np.asarray(pixel_ids, dtype=np.uint32))
+    return sd, ids, renderer.to_params(ids, A.FW_RNG_CTR)
+
+
+def render_counts(scene, renderer, pixel_ids=None, n_threads=0):
+    """Rays (root.hit calls) per pixel of a CTR render, pixel_ids order."""
+    lib = load()
+    sd, ids, p = _params(scene, renderer, pixel_ids)
+    n = int(ids.shape[0]) if ids is not None else p.width * p.height
+    out = np.zeros(n, np.uint32)
+    rc = lib.fwo_render_counts(sd.ptr(), C.byref(p), C.c_int(n_threads), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def path_lengths(scene, renderer, pixel, first_sample, n):
+    """Segments (1..11) of the paths of samples first_sample .. first_sample+n-1 of one pixel."""
+    lib = load()
+    sd, _, p = _params(scene, renderer)
+    out = np.zeros(n, np.uint8)
+    rc = lib.fwo_path_lengths(sd.ptr(), C.byref(p), C.c_uint32(pixel), C.c_uint32(first_sample), C.c_uint32(n), out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def trace_path(scene, renderer, pixel, sample):
+    """Every segment of one path: (11, 16) float32 rows = ray o, d | hit flag, t, material | point | normal | reached; + colour."""
+    lib = load()
+    sd, _, p = _params(scene, renderer)
+    out = np.zeros((11, 16), np.float32)
+    col = np.zeros(3, np.float32)
+    rc = lib.fwo_trace_path(sd.ptr(), C.byref(p), C.c_uint32(pixel), C.c_uint32(sample), out.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise OracleError(rc)
+    return out, col
