@@ -59,6 +59,8 @@ def load():
     lib.fw_release_workspace.argtypes = [C.c_int]
     lib.fw_selftest_arith.restype = C.c_int
     lib.fw_selftest_arith.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.fw_selftest_libm.restype = C.c_int
+    lib.fw_selftest_libm.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
     if lib.fw_abi_version() != A.FW_ABI_VERSION:
         raise FireworkError(A.FW_ERR_BAD_ARG, "ABI version mismatch between _abi.py and libfirework_hip.so")
     _lib = lib
@@ -75,6 +77,19 @@ def selftest_arith(n, seed=1, mode=0, device=0):
     d, s = C.c_uint64(), C.c_uint64()
     _check(lib, lib.fw_selftest_arith(device, n, seed, mode, C.byref(d), C.byref(s)))
     return int(d.value), int(s.value)
+
+
+LIBM_FN = dict(logf=0, log10f=1, sinf=2, asinf=3, acosf=4, atanf=5, atan2f=6, powf=7)
+
+
+def selftest_libm(fn, x, y=None, device=0):
+    """fw_selftest_libm: the device's restated glibc function `fn` over float32 arrays."""
+    lib = load()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    yy = None if y is None else np.ascontiguousarray(y, np.float32)
+    _check(lib, lib.fw_selftest_libm(device, LIBM_FN[fn], x.size, x.ctypes.data, None if yy is None else yy.ctypes.data, out.ctypes.data))
+    return out
 
 
 def release_workspace(device=0):

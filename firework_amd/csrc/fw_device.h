@@ -184,6 +184,7 @@ void launch_tile_order(hipStream_t stream, uint32_t width, uint32_t height, uint
 void launch_upload(hipStream_t stream, const void *pinned_src, void *dst, size_t bytes);
 void launch_count_deposits(const LaunchCfg &, const uint32_t *dep_bits, uint32_t *total);
 void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out);
+void launch_selftest_libm(hipStream_t stream, int fn, uint32_t n, const float *x, const float *y, float *out);
 void launch_accumulate(const LaunchCfg &, const DFrame &, const float4 *sample_rad, float4 *accum);
 void launch_resolve(const LaunchCfg &, const DFrame &, const float4 *accum, uint32_t total_spp, float gamma,
                     uint8_t *rgb8, float *gamma_rgb, float *linear_rgb);

@@ -22,7 +22,7 @@
 //
 // Numerics: compiled with -ffp-contract=off; +,-,*,/ and sqrt are IEEE-exact and written in the same
 // association as the reference's expressions, so hit/miss decisions follow the CPU oracle bit for
-// bit; only libm-class functions (sin, atan2, asin, log10, pow) differ by ulps.
+// bit; libm-class functions (sin, atan2, asin, acos, log10, pow) are glibc's algorithms restated (fw_libm.h): the same bits.
 #include "fw_device.h"
 #include "fw_libm.h"
 #include <atomic>
@@ -484,7 +484,7 @@ __device__ __forceinline__ bool hit_cone(float radius, float height, const Ray &
 __device__ __forceinline__ bool cylinder_ok(float height, float max_phi, const Ray &r, float t, float tmin, float tmax) {
     if (t > tmax || t < tmin) return false;
     V3 p = ray_point(r, t);
-    float phi = atan2f(p.z, p.x);
+    float phi = fwlm::atan2f_glibc(p.z, p.x);
     if (phi < 0.f) phi = phi + PI_F * 2.f;
     return p.y > 0.f && p.y < height && phi < max_phi;
 }
@@ -510,7 +510,7 @@ __device__ __forceinline__ bool hit_disk(float radius, float phi_max, float inne
     V3 p = ray_point(r, t);
     float dist2 = p.x * p.x + p.z * p.z;
     if (dist2 > radius * radius || dist2 < inner_radius * inner_radius) return false;
-    float phi = atan2f(p.z, p.x);
+    float phi = fwlm::atan2f_glibc(p.z, p.x);
     if (phi < 0.f) phi = phi + 2.f * PI_F;
     if (phi > phi_max) return false;
     t_out = t;
@@ -1756,13 +1756,13 @@ __device__ __forceinline__ V3 texture_sample(const float4 *texp, const uint8_t *
         case 0: return mk(t1.x, t1.y, t1.z);                                          // texture.rs:29-34
         case 1: {                                                                      // texture.rs:57-73
             float prod = 1.0f;
-            prod = prod * sinf(scale * p.x); prod = prod * sinf(scale * p.y); prod = prod * sinf(scale * p.z);
+            prod = prod * fwlm::sinf_glibc(scale * p.x); prod = prod * fwlm::sinf_glibc(scale * p.y); prod = prod * fwlm::sinf_glibc(scale * p.z);
             bool positive = (__float_as_uint(prod) >> 31) == 0u;                       // is_sign_positive
             tex = positive ? __float_as_uint(t1.x) : __float_as_uint(t0.w);
             continue; }
         case 2: { float a = perlin_noise(p * scale); float c = fminf(a + 0.5f, 1.f); return mk(c, c, c); }   // texture.rs:161-168
         case 3: { float c = turb(depth, p * scale); return mk(c, c, c); }                                    // texture.rs:219-225
-        case 4: { float c = 0.5f * (1.f + sinf(scale * p.z + 10.f * turb(depth, p))); return mk(c, c, c); }  // texture.rs:239-249
+        case 4: { float c = 0.5f * (1.f + fwlm::sinf_glibc(scale * p.z + 10.f * turb(depth, p))); return mk(c, c, c); }  // texture.rs:239-249
         case 5: {                                                                      // texture.rs:296-309
             uint32_t off = __float_as_uint(t1.x), w = __float_as_uint(t1.y), h = __float_as_uint(t1.z);
             float fi = u * (float)w, fj = (1.f - v) * (float)h;
@@ -1776,8 +1776,8 @@ __device__ __forceinline__ V3 texture_sample(const float4 *texp, const uint8_t *
 }
 
 __device__ __forceinline__ void sphere_uv(V3 p, float &u, float &v) {   // objects/sphere.rs:22-29
-    float phi = atan2f(p.z, p.x);
-    float theta = asinf(p.y);
+    float phi = fwlm::atan2f_glibc(p.z, p.x);
+    float theta = fwlm::asinf_glibc(p.y);
     u = 1.f - fdiv(phi + PI_F, 2.f * PI_F);
     v = fdiv(theta + PI_F / 2.f, PI_F);
 }
@@ -1810,7 +1810,7 @@ __device__ __forceinline__ bool refract(V3 v, V3 n, float ni_over_nt, V3 &out) {
 __device__ __forceinline__ float schlick(float cosine, float ref_idx) {                          // util.rs:69-73
     float r0 = fdiv(1.f - ref_idx, 1.f + ref_idx);
     r0 = r0 * r0;
-    return r0 + (1.f - r0) * powf(1.f - cosine, 5.f);
+    return r0 + (1.f - r0) * fwlm::powf_glibc(1.f - cosine, 5.f);
 }
 
 // rebuild the RaycastHit (render.rs:35-41) of the recorded (t, object, primitive) in world space
@@ -1900,20 +1900,20 @@ __device__ __forceinline__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, c
         V3 dpdu = mk(-p.z, 0.f, p.x);
         V3 dpdv = mk(fdiv(-p.x, omv), height, fdiv(-p.z, omv));
         n = normalized(cross(dpdv, dpdu));
-        if (need_uv) { h.u = fdiv(acosf(fdiv(p.x, radius * (1.f - v))), 2.f * PI_F); h.v = v; }
+        if (need_uv) { h.u = fdiv(fwlm::acosf_glibc(fdiv(p.x, radius * (1.f - v))), 2.f * PI_F); h.v = v; }
         break; }
     case 8: {                                                                          // cylinder.rs:66-78
         Rcp rr = make_rcp(o.q3.x);
         n = mk(fdiv(p.x, rr), 0.f, fdiv(p.z, rr));
         if (need_uv) {
-            float phi = atan2f(p.z, p.x);
+            float phi = fwlm::atan2f_glibc(p.z, p.x);
             if (phi < 0.f) phi = phi + PI_F * 2.f;
             h.u = fdiv(phi, o.q3.z); h.v = fdiv(p.y, o.q3.y);
         }
         break; }
     case 9: {                                                                          // disk.rs:60-82
         if (need_uv) {
-            float phi = atan2f(p.z, p.x);
+            float phi = fwlm::atan2f_glibc(p.z, p.x);
             if (phi < 0.f) phi = phi + 2.f * PI_F;
             h.u = fdiv(phi, o.q3.z);
             float dist = fsqrt(p.x * p.x + p.z * p.z);
@@ -2299,7 +2299,7 @@ __global__ __launch_bounds__(BLOCK) void k_resolve(DFrame f, const float4 *__res
         const uint32_t p = f.scatter_out ? f.pixel_ids[q] : q;                       // output index (the library's tile order is undone here)
         V3 total = mk(a.x, a.y, a.z) / (float)total_spp;                             // render.rs:184
         float ig = fdiv(1.f, gamma);
-        V3 g = mk(powf(total.x, ig), powf(total.y, ig), powf(total.z, ig));           // render.rs:186
+        V3 g = mk(fwlm::powf_glibc(total.x, ig), fwlm::powf_glibc(total.y, ig), fwlm::powf_glibc(total.z, ig));           // render.rs:186
         auto clamp01 = [](float x) { return (x != x) ? x : (x < 0.f ? 0.f : (x > 1.f ? 1.f : x)); };
         g = mk(clamp01(g.x), clamp01(g.y), clamp01(g.z));                             // render.rs:187
         if (linear_rgb) { linear_rgb[3 * (size_t)p] = total.x; linear_rgb[3 * (size_t)p + 1] = total.y; linear_rgb[3 * (size_t)p + 2] = total.z; }
@@ -2336,6 +2336,28 @@ __global__ __launch_bounds__(BLOCK) void k_selftest_arith(uint32_t n, uint32_t s
 }
 void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out) {
     hipLaunchKernelGGL(k_selftest_arith, dim3(1024), dim3(BLOCK), 0, stream, n, seed, mode, out);
+}
+// self-test: the libm-class functions of fw_libm.h evaluated on the device, element-wise: out[i] = fn(x[i] [, y[i]]).
+// fn: 0 logf 1 log10f 2 sinf 3 asinf 4 acosf 5 atanf 6 atan2f(x = y-argument, y = x-argument) 7 powf(x, y)
+__global__ __launch_bounds__(BLOCK) void k_selftest_libm(int fn, uint32_t n, const float *__restrict__ x, const float *__restrict__ y, float *__restrict__ out) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const float a = x[i], b = y ? y[i] : 0.f;
+        float r;
+        switch (fn) {
+        case 0: r = fwlm::logf_glibc(a); break;
+        case 1: r = fwlm::log10f_glibc(a); break;
+        case 2: r = fwlm::sinf_glibc(a); break;
+        case 3: r = fwlm::asinf_glibc(a); break;
+        case 4: r = fwlm::acosf_glibc(a); break;
+        case 5: r = fwlm::atanf_glibc(a); break;
+        case 6: r = fwlm::atan2f_glibc(a, b); break;
+        default: r = fwlm::powf_glibc(a, b); break;
+        }
+        out[i] = r;
+    }
+}
+void launch_selftest_libm(hipStream_t stream, int fn, uint32_t n, const float *x, const float *y, float *out) {
+    hipLaunchKernelGGL(k_selftest_libm, dim3(2048), dim3(BLOCK), 0, stream, fn, n, x, y, out);
 }
 
 // ------------------------------------------------------------------------------------------------

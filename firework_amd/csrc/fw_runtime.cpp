@@ -1159,6 +1159,30 @@ int fw_selftest_arith(int device, uint32_t n, uint32_t seed, int mode, uint64_t 
     return FW_OK;
 }
 
+int fw_selftest_libm(int device, int fn, uint32_t n, const float *x, const float *y, float *out) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(FW_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev || fn < 0 || fn > 7 || !x || !out || n == 0 || ((fn == 6 || fn == 7) && !y)) return fail(FW_ERR_BAD_ARG, "bad argument");
+    HIPCHK(hipSetDevice(device));
+    DevBuf dx, dy, dout;
+    int rc = dx.alloc((size_t)n * 4);
+    if (!rc && y) rc = dy.alloc((size_t)n * 4);
+    if (!rc) rc = dout.alloc((size_t)n * 4);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpy(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && y) e = hipMemcpy(dy.p, y, (size_t)n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            fw::launch_selftest_libm(nullptr, fn, n, (const float *)dx.p, y ? (const float *)dy.p : nullptr, (float *)dout.p);
+            e = hipMemcpy(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+        }
+    }
+    dx.release(); dy.release(); dout.release();
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(FW_ERR_HIP, hipGetErrorString(e));
+    return FW_OK;
+}
+
 int fw_scene_create(const fw_scene_desc *desc, int device, fw_scene **out) {
     try { return create_scene_impl(desc, device, out); }
     catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }

@@ -33,7 +33,8 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 4   /* 3: + fw_render_progressive; 4: fw_stats carries this layout's own HBM bytes per kernel class and the one-shot timings */
+#define FW_ABI_VERSION 5   /* 3: + fw_render_progressive; 4: fw_stats carries this layout's own HBM bytes per kernel class and the one-shot timings;
+                              5: + fw_selftest_libm; the 4th float of an accumulation record counts the path segments of the samples that deposited */
 
 /* ---- status codes ------------------------------------------------------ */
 typedef enum fw_status {
@@ -264,7 +265,8 @@ int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *par
 
 /* Progressive / resumable rendering (progressive preview, checkpointable accumulation buffer).
    Renders the samples [first_sample, first_sample + params->samples) of every pixel, adds them to `accum`
-   (n_pixels x 4 floats: r, g, b sums and one pad; all zeros before the first call; host memory, or device memory when
+   (n_pixels x 4 floats: r, g, b sums and the number of path segments of the samples that deposited a record — every sample
+   unless the environment is black, where zero deposits are elided; all zeros before the first call; host memory, or device memory when
    params->outputs_on_device) and resolves accum / (first_sample + samples) into the output buffers (any may be NULL).
    Every random draw is keyed by (pixel, ABSOLUTE sample index) and a pixel's sums are taken in sample order, so k calls
    of n samples leave bit for bit the accum and the image of one call of k*n samples — whatever is done with `accum`
@@ -285,6 +287,12 @@ void fw_release_workspace(int device);
 /* Diagnostic: the kernels' division / square-root helpers against the compiler's IEEE expansion, bit for bit,
    on n hashed operand pairs.  mode 0 = magnitudes 2^-40..2^40 (must be 0 mismatches), mode 1 = all bit patterns. */
 int fw_selftest_arith(int device, uint32_t n, uint32_t seed, int mode, uint64_t *div_mismatches, uint64_t *sqrt_mismatches);
+
+/* Diagnostic: the libm-class functions of the path (firework_amd/csrc/fw_libm.h: glibc's logf, log10f, sinf, asinf, acosf,
+   atanf, atan2f, powf restated for the device) evaluated on the device, element-wise, on host arrays: out[i] = fn(x[i] [, y[i]]).
+   fn: 0 logf  1 log10f  2 sinf  3 asinf  4 acosf  5 atanf  6 atan2f(x[i], y[i]) = atan2(first, second)  7 powf(x[i], y[i]).
+   y may be NULL for the one-argument functions.  tests/test_gpu_libm.py compares the results with the host's libm bit for bit. */
+int fw_selftest_libm(int device, int fn, uint32_t n, const float *x, const float *y, float *out);
 
 #ifdef __cplusplus
 }

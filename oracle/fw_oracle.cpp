@@ -1147,6 +1147,27 @@ int fwo_trace_path(const fw_scene_desc *desc, const fw_render_params *params, ui
     return FW_OK;
 }
 
+// The host's libm, element-wise — what the reference's f32::ln / log10 / sin / asin / acos / atan / atan2 / powf lower to on
+// this platform, and what the device's restatements (firework_amd/csrc/fw_libm.h) are compared with (tests/test_gpu_libm.py).
+// fn: 0 logf 1 log10f 2 sinf 3 asinf 4 acosf 5 atanf 6 atan2f(x[i], y[i]) 7 powf(x[i], y[i])
+int fwo_libm(int fn, uint32_t n, const float *x, const float *y, float *out) {
+    if (!x || !out || fn < 0 || fn > 7 || ((fn == 6 || fn == 7) && !y)) return FW_ERR_BAD_ARG;
+    for (uint32_t i = 0; i < n; i++) {
+        const float a = x[i], b = y ? y[i] : 0.f;
+        switch (fn) {
+        case 0: out[i] = std::log(a); break;
+        case 1: out[i] = std::log10(a); break;
+        case 2: out[i] = std::sin(a); break;
+        case 3: out[i] = std::asin(a); break;
+        case 4: out[i] = std::acos(a); break;
+        case 5: out[i] = std::atan(a); break;
+        case 6: out[i] = std::atan2(a, b); break;
+        default: out[i] = std::pow(a, b); break;
+        }
+    }
+    return FW_OK;
+}
+
 // ---- unit-level probes for known-answer tests -------------------
 void fwo_coord_from_index(uint64_t idx, uint64_t w, uint64_t h, uint64_t out[2]) { out[0] = idx % w; out[1] = h - idx / w; }
 void fwo_color_from_vec3(const float c[3], uint8_t out[3]) { for (int i = 0; i < 3; i++) out[i] = sat_u8(c[i] * 255.99f); }

@@ -268,3 +268,19 @@ def trace_path(scene, renderer, pixel, sample):
     if rc:
         raise OracleError(rc)
     return out, col
+
+
+LIBM_FN = dict(logf=0, log10f=1, sinf=2, asinf=3, acosf=4, atanf=5, atan2f=6, powf=7)
+
+
+def libm(fn, x, y=None):
+    """The host libm's float function `fn` over float32 arrays (what the reference's f32 methods call on this platform)."""
+    lib = load()
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    yy = None if y is None else np.ascontiguousarray(y, np.float32)
+    rc = lib.fwo_libm(C.c_int(LIBM_FN[fn]), C.c_uint32(x.size), x.ctypes.data_as(C.c_void_p), None if yy is None else yy.ctypes.data_as(C.c_void_p),
+                      out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise OracleError(rc)
+    return out

@@ -69,6 +69,12 @@ def main():
         key = name.split(".")[0]
         lat[key] = np.ascontiguousarray(im[stride // 2::stride, stride // 2::stride])
         lat[key + "_meta"] = np.array([im.shape[1], im.shape[0], stride], np.int32)      # width, height, stride
+    # part2_final.png (600x800, examples/part2_all.rs): the 190x190 window around the TurbulenceTexture sphere, every pixel —
+    # box heights and the 1000 small spheres come from tiny_rng (not in the tree), the noise pattern on the sphere does not
+    im = np.asarray(Image.open(f"{REF}/part2_final.png").convert("RGB"), np.uint8)
+    assert im.shape == (800, 600, 3)
+    lat["part2_turbulence_window"] = np.ascontiguousarray(im[325:515, 180:370])
+    lat["part2_turbulence_window_meta"] = np.array([600, 800, 180, 325, 370, 515], np.int32)     # width, height, x0, y0, x1, y1
     np.savez_compressed(f"{ROOT}/tests/golden/reference_png_lattice.npz", **lat)
     shutil.copyfile(f"{REF}/uvmap.png", f"{ROOT}/scenes/uvmap.png")
 

@@ -16,11 +16,16 @@ Each image is compared at gamma 2.2 (render.rs:214, today's default) AND at gamm
   conics.png       conics.rs 960x540 @128           2.2      Cone / Cylinder / Disk, ImageTexture, from_euler_angles, flip_normals
   Earth.png        earth.rs 800x800 @128            2.2      Sphere + sphere_uv + ImageTexture (jpg and png)
   teapot.png       teapot.rs 1920x1080 @512 BVH     2.2      smooth-normal meshes (mesh.rs:206-207), 4 BLASes
-  volume.png       volume_test.rs 960x540 @2048     2.2      sky / floor / light only: the PNG shows a sphere of radius ~1.5
-                                                             sunk into the floor, today's example has radius 1.0 at y=1
+  volume.png       volume_test.rs 960x540 @2048     2.2      ConstantMedium (log10 free path), IsotropicMat, DielectricMat — with the
+                                                             example's radii at 1.5 / 1.51 (the PNG predates today's 1.0 / 1.01)
 
-Not usable: random_spheres.png (layout from tiny_rng::Rng, not in the tree), hdri_test.png (its .hdr is not in the
-tree), part2_final.png (example no longer compiles against src/), heightmap.png (out of scope).
+  part2_final.png  part2_all.rs 600x800 @10000 BVH  2.2      the TurbulenceTexture sphere's pattern only (Perlin noise, turbulence): box
+                                                             heights and the small spheres come from tiny_rng, the example is API-stale
+
+Not usable: random_spheres.png (its camera is not the example's: the horizon sits on row 169 instead of 182, the metal sphere
+has radius 119 px instead of 106 and its centre is 19 px further right — not a pure zoom — and the checker squares are larger;
+with the layout from tiny_rng on top, nothing in it can be compared without fitting four or more unknowns), hdri_test.png
+(its .hdr is not in the tree), heightmap.png (out of scope).
 """
 import os
 
@@ -112,16 +117,54 @@ def test_teapot_png(oracle):
     assert out[2.0][0] > 3.0 * out[2.2][0]
 
 
-def test_volume_png_outside_the_sphere(oracle):
-    """examples/volume_test.rs:11-67.  The committed PNG was rendered from an earlier scene: its sphere has radius ~1.5 and
-    is sunk into the floor (a silhouette of radius 1.5 at (0,1,0) overlaps it with IoU 0.98; today's radius 1.0 gives
-    0.48), so the ConstantMedium / glass pixels cannot be compared.  Sky, horizon, floor and the light's glow on the
-    floor — everything more than ~2.2 sphere radii from the sphere's column — are the same scene and must agree."""
-    out, maps = _compare(oracle, "volume", *scenes.volume_test(), spp=512)
-    _report("volume.png", out)
+def test_volume_png_pins_the_medium_and_the_glass(oracle):
+    """examples/volume_test.rs:11-67.  The committed PNG was rendered when the example's two radii were 1.5 and 1.51 instead
+    of today's 1.0 and 1.01 — nothing else differs: with `Sphere::new(1.5, ..)` for the medium at (0,1,0) and
+    `Sphere::new(1.51, glass)` at (0,1,1) the oracle reproduces the WHOLE image, the sphere included, to half a grey level
+    per block: the silhouette (radius 1.5 fits with IoU 0.98, today's 1.0 with 0.48), the inner circle (the glass sphere
+    behind, seen through the medium: 1.51 * 10.2 / 11.2 = 0.92 of the outer radius), the faint reflection of the light and
+    the purple itself.  That makes volume.png the reference output for three classes nothing else pins:
+      * ConstantMedium's free path -(1/density) * log10(xi) (volume.rs:67): with ln instead (the same medium at density
+        0.5 / ln 10) the sphere's blocks are off by 26 grey levels in the mean and 76 in the worst block;
+      * IsotropicMat (material.rs:197-204): the colour of the medium;
+      * DielectricMat (material.rs:121-151, util.rs:58-73): without the glass sphere the blocks it covers are off by 5 (19)."""
+    import math
+    out, maps = _compare(oracle, "volume", *scenes.volume_test(1.5, 1.51), spp=512)
+    _report("volume.png (radii 1.5 / 1.51)", out)
     d = maps[2.2]
-    cols = np.ones(d.shape[1], bool)
-    cols[4:12] = False                               # 16 block columns; the sphere, its shadow and caustic sit in 4..11
-    assert d[:, cols].mean() < 1.0 and d[:, cols].max() < 3.5
-    assert d[6:, :].mean() < 1.5 and d[6:, :].max() < 3.5      # the floor in front of the sphere, all columns
-    assert maps[2.0][:, cols].mean() > 3.0 * d[:, cols].mean()
+    sphere = (slice(0, 6), slice(4, 12))                       # the 8 x 6 blocks the sphere, its shadow and caustic touch
+    assert d.mean() < 1.0 and d.max() < 3.5
+    assert d[sphere].mean() < 1.0 and d[sphere].max() < 2.5
+    assert maps[2.0].mean() > 3.0 * d.mean()                   # written at gamma 2.2
+    # the alternatives the image rules out
+    _, m_ln = _compare(oracle, "volume", *scenes.volume_test(1.5, 1.51, density=0.5 / math.log(10.0)), spp=128)
+    assert m_ln[2.2][sphere].mean() > 15.0, "a natural-log free path would look like this"
+    _, m_ng = _compare(oracle, "volume", *scenes.volume_test(1.5, with_glass=False), spp=128)
+    assert m_ng[2.2][sphere].mean() > 3.0 and m_ng[2.2][sphere].max() > 10.0, "the glass sphere is in the picture"
+    _, m_today = _compare(oracle, "volume", *scenes.volume_test(), spp=128)
+    assert m_today[2.2][sphere].mean() > 20.0, "today's radii (1.0 / 1.01) are not what the PNG shows"
+
+
+def test_part2_final_png_pins_the_turbulence_pattern(oracle):
+    """examples/part2_all.rs:57-59 — `TurbulenceTexture::new(5, 10.)` on the sphere of radius 0.8 at (2.2, 2.8, 3.0).  The example
+    is API-stale and its box heights and 1 000 small spheres come from tiny_rng (not in the tree), so part2_final.png cannot be
+    compared as a whole — but the noise on that sphere depends on nothing random: Perlin's permutation table, the smoothstep
+    fade, the `as usize & 255` lattice, turbulence WITHOUT abs (texture.rs:80-225), the camera, the sphere.  Where turb <= 0 the
+    albedo is <= 0 and the pixel is black whatever the light does (a negative mean is NaN after powf and 0 after `as u8`), so
+    the BLACK / NOT BLACK map of the sphere is compared (192 spp here against the PNG's 10 000): it agrees on 93 % of the sphere's pixels (a wrong phase would give
+    ~58 %: the same map shifted by 6 pixels), luminance correlation 0.95.  The only reference output Perlin / Turbulence have."""
+    win = LATTICE["part2_turbulence_window"].astype(np.float64)
+    width, height, x0, y0, x1, y1 = (int(v) for v in LATTICE["part2_turbulence_window_meta"])
+    scene, renderer = scenes.part2_all()
+    renderer.width(width).height(height).samples(192)
+    ys, xs = np.meshgrid(np.arange(y0, y1), np.arange(x0, x1), indexing="ij")
+    res = oracle.render(scene, renderer, pixel_ids=(ys * width + xs).reshape(-1).astype(np.uint32))
+    lin = np.clip(np.nan_to_num(res.linear.astype(np.float64)), 0.0, None)
+    img = np.floor(np.clip(lin ** (1.0 / 2.2), 0.0, 1.0) * 255.99).reshape(ys.shape + (3,))
+    inside = np.hypot(xs - 274, ys - 421) < 70                    # the sphere's disc, a few pixels inside its rim
+    ref_black, our_black = win.mean(2) < 12, img.mean(2) < 12
+    agree = float((ref_black[inside] == our_black[inside]).mean())
+    shifted = float((ref_black[inside] == np.roll(our_black, 6, axis=1)[inside]).mean())
+    corr = float(np.corrcoef(win.mean(2)[inside], img.mean(2)[inside])[0, 1])
+    print(f"\npart2_final.png turbulence sphere: black-map agreement {agree:.3f} (shifted by 6 px: {shifted:.3f}), luminance correlation {corr:.3f}")
+    assert agree > 0.85 and shifted < 0.68 and corr > 0.85
