@@ -88,9 +88,35 @@ struct DScene {
     uint32_t has_perlin;          // some texture is PerlinNoise / Turbulence / Marble: k_shade stages the permutation table in LDS
     uint32_t has_mesh;
     uint32_t prim_bits;       // hit code = object << prim_bits | primitive
+    const float4 *ref_tlas;   // the REFERENCE trees (host FlatBvh format below: 2 x float4 per node, DFS order), walked only by
+    const float4 *ref_blas;   // k_extend_exact; ref_blas holds every mesh's tree, child indices relative to the mesh's first node
+    const uint32_t *obj_ref_blas;   // per object: first node of its mesh's reference tree in ref_blas (meshes and media around meshes)
     uint32_t n_hoisted;       // objects kept OUT of the walked TLAS because nearly every ray meets their box (part2's fog sphere
     uint32_t hoisted[4];      // around the whole scene): tested for every ray, wave-uniformly, before the walk (hoisted_hits)
     DEnv env;
+};
+
+// ---- the exact walk (k_extend_exact).  A ray whose result depends on HOW the trees are walked — not on where it goes — is
+// flagged when it is made (k_raygen / k_shade) and traced a second time by the literal algorithm of bvh.rs:115-151 over the
+// reference's own trees (median split, node boxes, DoubleLeaf = both items behind one box, both children always, no culling);
+// that result replaces the fast walk's.  Two classes, both found by tools/diverge.py:
+//   mode & 1  ill-conditioned triangle shears (scenes with meshes): mesh.rs:147-162 permutes the axes by the SIGNED largest
+//             direction component (util.rs:104-118), so a ray like (-0.88, 0.00016, -0.41) divides by 0.00016: shear factors
+//             of ~5000, edge functions that are rounding noise, "hits" whose t lies outside the triangle's box.  Which of
+//             those a walk finds depends on the boxes it passes and on culling.  Flagged: |d_kz| < 2^-10 max|d_i| in the world
+//             frame or in the frame of a rotated mesh (up to four distinct rotations).
+//   mode & 2  far origins (use_bvh): from 1000 units away a sphere of radius 0.1 has a discriminant that is the difference of two
+//             numbers near 2*10^6 — noise — and the reference tests it whenever the ray passes the box of its DoubleLeaf node,
+//             a front-to-back walk when it passes the sphere's own box.  Flagged: origin farther than far_r from the cluster
+//             of the scene's small objects AND the ray passes that cluster's (inflated) box.
+struct DExact {
+    uint32_t mode;
+    uint32_t n_frames;            // distinct rotations of mesh objects (<= 4), rows of rotation_mat
+    float frames[4][9];
+    float far_c[3], far_r;        // centre of the small-object cluster, distance beyond which an origin is "far"
+    float box_lo[3], box_hi[3];   // the cluster's box, inflated
+    uint32_t *bits;               // one bit per path slot of the NEXT segment's queue: "trace this ray exactly"; zeroed per batch,
+                                  // cleared by k_extend_exact as it consumes them
 };
 
 struct DCamera {   // camera.rs:7-16
@@ -116,6 +142,7 @@ struct DFrame {
     uint32_t hit4;                // 4-byte hit records (the code only): k_shade recomputes t.  Linear scan, scenes of spheres / rects / Rect3d only
     uint32_t pinhole0;            // aperture 0: every camera ray starts at cam_pos, segment-0 rays are stored as 16 B (direction only)
     float cam_pos[3];
+    DExact ex;                    // which rays are traced a second time by the literal reference walk
 };
 
 // ---- wavefront path state, SoA over path slots (DESIGN.md §"Path state")
@@ -173,6 +200,8 @@ constexpr size_t LDS_TABLE_LIMIT = 16 * 1024;   // object+material+texture table
 
 void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, float4 *sample_rad, uint32_t n_paths);
 void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float2 *hits, int segment, bool use_bvh, DPark park);
+void launch_extend_exact(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float2 *hits, int segment, bool use_bvh,
+                         uint32_t *list, uint32_t *count);   // count: this segment's own counter (zeroed per batch)
 void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment);
 void launch_bounce(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, float4 *sample_rad, int segment,

@@ -222,6 +222,41 @@ __device__ __forceinline__ float4 load_state(const DPaths &in, uint32_t i, int s
 }
 
 // ------------------------------------------------------------------------------------------------
+// The exact walk's flag rule (fw_device.h DExact): does this ray's result depend on how the trees are walked?
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ill_direction(float dx, float dy, float dz) {
+    // util.rs:104-118 picks the SIGNED largest component as the shear axis of mesh.rs:147-162
+    const float dk = dx > dy ? (dz > dx ? dz : dx) : (dz > dy ? dz : dy);
+    const float am = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+    return fabsf(dk) < am * (1.0f / 1024.0f);
+}
+__device__ __forceinline__ bool needs_exact(const DExact &ex, float ox, float oy, float oz, float dx, float dy, float dz) {
+    if (ex.mode & 4u) return true;
+    if (ex.mode & 1u) {
+        if (ill_direction(dx, dy, dz)) return true;
+        for (uint32_t k = 0; k < ex.n_frames; k++) {            // inv_rotation_mat * d = rows of rotation_mat as columns (rot_inv)
+            const float *m = ex.frames[k];
+            if (ill_direction(m[0] * dx + m[3] * dy + m[6] * dz, m[1] * dx + m[4] * dy + m[7] * dz, m[2] * dx + m[5] * dy + m[8] * dz)) return true;
+        }
+    }
+    if (ex.mode & 2u) {
+        const float far = fmaxf(fmaxf(fabsf(ox - ex.far_c[0]), fabsf(oy - ex.far_c[1])), fabsf(oz - ex.far_c[2]));
+        if (far > ex.far_r) {       // a far origin: does the ray come near the small objects at all?  (conservative slab test)
+            const float ix = __builtin_amdgcn_rcpf(dx), iy = __builtin_amdgcn_rcpf(dy), iz = __builtin_amdgcn_rcpf(dz);
+            float t0 = (ex.box_lo[0] - ox) * ix, t1 = (ex.box_hi[0] - ox) * ix;
+            float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+            t0 = (ex.box_lo[1] - oy) * iy; t1 = (ex.box_hi[1] - oy) * iy;
+            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+            t0 = (ex.box_lo[2] - oz) * iz; t1 = (ex.box_hi[2] - oz) * iz;
+            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+            if (!(tf < tn * (1.f - 1e-3f)) && !(tf < 0.f)) return true;
+        }
+    }
+    return false;
+}
+__device__ __forceinline__ void flag_exact(const DExact &ex, uint32_t slot) { atomicOr(&ex.bits[slot >> 5], 1u << (slot & 31u)); }
+
+// ------------------------------------------------------------------------------------------------
 // K1  ray generation
 // ------------------------------------------------------------------------------------------------
 constexpr int WB = FW_WB;
@@ -302,6 +337,7 @@ __global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out
                 qst(&out.ray_a[slot], make_float4(o.x, o.y, o.z, d.x));
                 qst(&out.ray_b[slot], make_float2(d.y, d.z));
             }
+            if (f.ex.mode && needs_exact(f.ex, o.x, o.y, o.z, d.x, d.y, d.z)) flag_exact(f.ex, slot);
         }
         produced += min(64u, n_paths - id0);
     }
@@ -672,7 +708,41 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
     return have;
 }
 
-// shape dispatch in object space.  prim: rect3d face / mesh triangle, else 0.
+// The literal mesh walk of the reference (bvh.rs:115-151 over mesh.rs's Triangle items) for k_extend_exact: the mesh's own
+// median-split tree, a node's items tested whenever the ray passes the NODE's box (a DoubleLeaf holds two behind one box),
+// both children always, nothing culled; the smaller t wins, a tie goes to the later item (`if lh.t < rh.t {lh} else {rh}`).
+// ref_root = first node of the mesh's tree in sc.ref_blas (child indices are relative to it).
+__device__ bool hit_mesh_exact(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
+                               float &t_out, uint32_t &tri_out) {
+    const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));      // aabb.rs:33: 1.0 / r.direction()[a]
+    const TriRay tr = make_triray(r);
+    const float4 *nodes = sc.ref_blas + 2 * (size_t)ref_root;
+    uint32_t stack[48]; int sp = 0;
+    uint32_t cur = 0; bool have = false; float best = tmax; uint32_t best_tri = 0;
+    for (;;) {
+        const float4 lo = nodes[2 * (size_t)cur], hi = nodes[2 * (size_t)cur + 1];
+        const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w), kind = A >> 30;
+        if (hit_aabb(lo, hi, r.o, inv, tmin, tmax)) {
+            if (kind == 0u) { if (sp < 48) stack[sp++] = A & NODE_MASK; cur = cur + 1u; continue; }     // Branch: left = next node, right later
+            const uint32_t items[2] = {A & NODE_MASK, B};
+            for (uint32_t k = 0; k < (kind == NODE_DOUBLE ? 2u : 1u); k++) {
+                const float4 *tp = sc.tri + 3 * (size_t)(tri_base + items[k]);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, b0, b1, b2;
+                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, tmin, tmax, t, b0, b1, b2))
+                    if (!have || !(best < t)) { have = true; best = t; best_tri = items[k]; }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    t_out = best; tri_out = best_tri;
+    return have;
+}
+
+// shape dispatch in object space.  prim: rect3d face / mesh triangle, else 0.  EXACT: a mesh takes the literal reference walk
+// and aux0 is its reference tree's first node (k_extend_exact).
+template <bool EXACT = false>
 __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float4 q3, float4 q4, uint32_t aux0, uint32_t aux1,
                                           const Ray &r, float tmin, float tmax, uint32_t *stack_base, float &t, uint32_t &prim) {
     prim = 0;
@@ -680,7 +750,8 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
     case 0: return hit_sphere(q3.x, r, tmin, tmax, t);
     case 1: case 2: case 3: return hit_rect_kind(kind, q3, q4, r, tmin, tmax, t);
     case 4: return hit_rect3d(q3, q4, r, tmin, tmax, t, prim);
-    case 5: return hit_mesh(sc, aux0, aux1, r, tmin, tmax, tmax, stack_base, t, prim);
+    case 5: if (EXACT) return hit_mesh_exact(sc, aux0, aux1, r, tmin, tmax, t, prim);
+            return hit_mesh(sc, aux0, aux1, r, tmin, tmax, tmax, stack_base, t, prim);
     case 7: return hit_cone(q3.x, q3.y, r, tmin, tmax, t);
     case 8: return hit_cylinder(q3.x, q3.y, q3.z, r, tmin, tmax, t);
     case 9: return hit_disk(q3.x, q3.z, q3.w, r, tmin, tmax, t);
@@ -689,13 +760,15 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
 }
 
 // objects/volume.rs:56-82
+template <bool EXACT = false>
 __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const Ray &r, float tmin, float tmax,
                                            uint32_t *stack_base, const RngKey &key, uint32_t segment, uint32_t obj_index, float &t_out) {
     const float FMAX = 3.40282347e+38f;
     uint32_t ik = obj_inner(o), prim;
     float t1, t2;
-    if (!hit_shape(sc, ik, o.q3, o.q4, o.aux0, o.aux1, r, -FMAX, FMAX, stack_base, t1, prim)) return false;
-    if (!hit_shape(sc, ik, o.q3, o.q4, o.aux0, o.aux1, r, t1 + 0.0001f, FMAX, stack_base, t2, prim)) return false;
+    const uint32_t root = EXACT ? sc.obj_ref_blas[obj_index] : o.aux0;
+    if (!hit_shape<EXACT>(sc, ik, o.q3, o.q4, root, o.aux1, r, -FMAX, FMAX, stack_base, t1, prim)) return false;
+    if (!hit_shape<EXACT>(sc, ik, o.q3, o.q4, root, o.aux1, r, t1 + 0.0001f, FMAX, stack_base, t2, prim)) return false;
     t1 = fmaxf(t1, tmin);
     t2 = fminf(t2, tmax);
     if (t1 >= t2) return false;
@@ -711,13 +784,14 @@ __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const
 // RenderObjectInternal::hit up to the object-space t (the world-space point/normal are rebuilt in k_shade)
 // MEDIUM = false: the caller's scene holds no ConstantMedium (k_extend_linear_defer: the host checks), so the medium's code —
 // its double-precision log10 costs registers even where it never runs — is compiled out
-template <bool MEDIUM = true>
+template <bool MEDIUM = true, bool EXACT = false>
 __device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint32_t obj_index, const Ray &world, float tmin,
                                            float tmax, uint32_t *stack_base, const RngKey &key, uint32_t segment, float &t, uint32_t &prim) {
     Ray r = to_object_space(o, world);
     uint32_t kind = obj_kind(o);
-    if (MEDIUM && kind == 6) { prim = 0; return hit_medium(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
-    return hit_shape(sc, kind, o.q3, o.q4, o.aux0, o.aux1, r, tmin, tmax, stack_base, t, prim);
+    if (MEDIUM && kind == 6) { prim = 0; return hit_medium<EXACT>(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
+    const uint32_t root = (EXACT && kind == 5u) ? sc.obj_ref_blas[obj_index] : o.aux0;
+    return hit_shape<EXACT>(sc, kind, o.q3, o.q4, root, o.aux1, r, tmin, tmax, stack_base, t, prim);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1688,6 +1762,73 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
 }
 
 // ------------------------------------------------------------------------------------------------
+// K2-exact  k_extend_exact: the flagged rays of a segment (DExact, fw_device.h) traced once more by the literal algorithm of
+// the reference — scene.rs:137-149 (linear) or bvh.rs:115-151 over the reference's OWN trees (use_bvh) — after the fast
+// kernels; its hit records replace theirs.  One flag bit per slot, set by k_raygen / k_shade, consumed here.  The flagged
+// rays are a few per million (ill-conditioned triangle shears, noise hits from far away), so this kernel's speed does not
+// matter and it is written for clarity: private stacks, nodes from L2.
+// With FIREWORK_EXACT_ALL=1 every ray takes it: the renderer then IS the reference's traversal (tests, tools/diverge.py).
+// ------------------------------------------------------------------------------------------------
+__device__ void closest_hit_exact(const DScene &sc, const Ray &r, const RngKey &key, int segment, bool use_bvh,
+                                  float &best_t, uint32_t &best_obj, uint32_t &best_prim) {
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    best_t = TMAX; best_obj = MISS; best_prim = 0;
+    if (!use_bvh) {                                                  // scene.rs:137-149: in order, narrowing, a later object replaces
+        for (uint32_t k = 0; k < sc.n_objects; k++) {
+            const Obj o = load_obj(sc.obj, k);
+            float t; uint32_t prim;
+            if (hit_object<true, true>(sc, o, k, r, TMIN, best_t, nullptr, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+        }
+        return;
+    }
+    const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+    uint32_t stack[48]; int sp = 0;
+    uint32_t cur = 0; bool have = false;
+    for (;;) {
+        const float4 lo = sc.ref_tlas[2 * (size_t)cur], hi = sc.ref_tlas[2 * (size_t)cur + 1];
+        const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w), kind = A >> 30;
+        if (hit_aabb(lo, hi, r.o, inv, TMIN, TMAX)) {
+            if (kind == 0u) { if (sp < 48) stack[sp++] = A & NODE_MASK; cur = cur + 1u; continue; }
+            const uint32_t items[2] = {A & NODE_MASK, B};
+            for (uint32_t k = 0; k < (kind == NODE_DOUBLE ? 2u : 1u); k++) {
+                const Obj o = load_obj(sc.obj, items[k]);
+                float t; uint32_t prim;
+                if (hit_object<true, true>(sc, o, items[k], r, TMIN, TMAX, nullptr, key, segment, t, prim))
+                    if (!have || !(best_t < t)) { have = true; best_t = t; best_obj = items[k]; best_prim = prim; }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+}
+// Two launches per segment: k_exact_scan reads the flag bitmap (one bit per slot, 1/256 of the queue bytes), clears it and
+// appends the flagged slots to one dense list; k_extend_exact walks the listed rays, one per lane, every lane busy.  (The first
+// version did both in one kernel, each wave for its own queue: a wave with ONE flagged ray then walked it with one lane
+// while the GPU waited — suzanne 72.7 -> 87.1 ms.)
+__global__ __launch_bounds__(BLOCK) void k_exact_scan(uint32_t *__restrict__ bits, uint32_t n_words, uint32_t *__restrict__ list, uint32_t *__restrict__ count) {
+    for (uint32_t wi = blockIdx.x * BLOCK + threadIdx.x; wi < n_words; wi += gridDim.x * BLOCK) {
+        uint32_t word = bits[wi];
+        if (!word) continue;
+        bits[wi] = 0u;                                               // consumed: the next segment's flags go into clean words
+        uint32_t at = atomicAdd(count, (uint32_t)__popc(word));
+        while (word) { const uint32_t b = (uint32_t)__ffs((int)word) - 1u; word &= word - 1u; list[at++] = wi * 32u + b; }
+    }
+}
+__global__ __launch_bounds__(WB) void k_extend_exact(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, int segment, int use_bvh,
+                                                     const uint32_t *__restrict__ list, const uint32_t *__restrict__ count) {
+    const uint32_t n = *count;
+    for (uint32_t k = blockIdx.x * WB + threadIdx.x; k < n; k += gridDim.x * WB) {
+        const uint32_t i = list[k];
+        const Ray r = make_ray(qld(&in.ray_a[i]), load_ray_b(in, i, f, segment), f, segment);
+        RngKey key{0, 0, 0};
+        if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
+        float best_t; uint32_t best_obj, best_prim;
+        closest_hit_exact(sc, r, key, segment, use_bvh != 0, best_t, best_obj, best_prim);
+        hits[i] = pack_hit(best_t, best_obj, best_prim, sc.prim_bits);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K5/K6  shading: textures, materials, environment
 // ------------------------------------------------------------------------------------------------
 __constant__ __attribute__((aligned(4))) uint8_t PERM[256] = {   // texture.rs:80-106
@@ -2069,6 +2210,7 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
             qst(&out.ray_a[dst], make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x));
             qst(&out.ray_b[dst], make_float2(nr.d.y, nr.d.z));
             qst(&out.state[dst], make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id)));
+            if (f.ex.mode && needs_exact(f.ex, nr.o.x, nr.o.y, nr.o.z, nr.d.x, nr.d.y, nr.d.z)) flag_exact(f.ex, dst);
         }
         out_n += (uint32_t)__popcll(mask);
     }
@@ -2416,6 +2558,12 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)(DEFER0_CAP + DEFER1_CAP) * 12, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+}
+void launch_extend_exact(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float2 *hits, int segment, bool use_bvh,
+                         uint32_t *list, uint32_t *count) {
+    const uint32_t n_words = (c.q.n_waves * c.q.cap + 31u) / 32u;
+    hipLaunchKernelGGL(k_exact_scan, dim3(std::min<uint32_t>((n_words + BLOCK - 1) / BLOCK, (uint32_t)c.n_cus * 8u)), dim3(BLOCK), 0, c.stream, f.ex.bits, n_words, list, count);
+    hipLaunchKernelGGL(k_extend_exact, dim3((uint32_t)c.n_cus * 8u), dim3(WB), 0, c.stream, sc, f, in, hits, segment, use_bvh ? 1 : 0, list, count);
 }
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment) {

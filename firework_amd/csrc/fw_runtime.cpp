@@ -277,7 +277,7 @@ struct DevBuf {
 // depend on n (batches are accumulated in order).  Default 1: the measured gain is ~3 %.
 struct Workspace {
     static constexpr int MAX_LANES = 4;
-    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, wcount, park_a, park_b, park_m, pcount, dep_bits;
+    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, wcount, park_a, park_b, park_m, pcount, dep_bits, exact_bits, exact_list;
                   hipStream_t stream = nullptr; std::vector<hipEvent_t> events; };
     std::mutex mu;                        // one fw_render at a time per device
     Lane lanes[MAX_LANES];
@@ -297,7 +297,7 @@ struct Workspace {
         tile_ids.release(); tile_w = tile_h = 0;
         for (DevBuf *b : {&accum, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear, &scene_cache}) b->release();
         for (Lane &l : lanes) {
-            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount, &l.park_a, &l.park_b, &l.park_m, &l.pcount, &l.dep_bits}) b->release();
+            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount, &l.park_a, &l.park_b, &l.park_m, &l.pcount, &l.dep_bits, &l.exact_bits, &l.exact_list}) b->release();
             for (hipEvent_t e : l.events) (void)hipEventDestroy(e);
             l.events.clear();
             if (l.stream) (void)hipStreamDestroy(l.stream);
@@ -329,6 +329,8 @@ struct fw_scene {
     uint32_t n_defer = 0;
     bool simple_shapes = false;   // every object is a sphere, an axis-aligned rect or a Rect3d (no medium, mesh, cone, cylinder, disk)
     bool hdr_env = false;
+    fw::DExact ex{};              // flag rule of the exact walk (bits pointer is per render)
+    uint32_t ref_tlas_depth = 0, ref_blas_depth = 0;
     ~fw_scene() {
         data.release();
     }
@@ -337,6 +339,7 @@ struct fw_scene {
 namespace {
 
 struct ShapeParams { float q3[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0}; uint32_t kind = 0, flags = 0, aux0 = 0, aux1 = 0; Box box{};
+                     uint32_t ref_root = 0xffffffffu, n_tris = 0;   // meshes: first node of the reference tree in Flattener::ref_blas
                      Box true_box{}; };   // OF_GATE shapes: a box that really encloses the geometry (object space)
 
 struct Flattener {
@@ -345,6 +348,8 @@ struct Flattener {
     std::vector<uint32_t> tri_rank;       // in-order rank of each triangle in the reference tree of its mesh
     bool any_attr = false;
     PairBvh blas;                 // all meshes' trees, as walked on the device
+    std::vector<float> ref_blas;  // all meshes' REFERENCE trees (FlatBvh nodes, 8 floats each; child indices relative to the mesh's first node)
+    uint32_t ref_blas_depth = 0;
     uint32_t blas_depth = 0, ref_blas_nodes = 0, max_tris = 0;
     std::vector<ShapeParams> mesh_cache;  // per shape index: a TriangleMesh shape referenced by several objects (or by a medium
     std::vector<uint8_t> mesh_cached;     // and an object) is flattened and built once, every user shares its triangles and BLAS
@@ -455,6 +460,9 @@ struct Flattener {
             tri_rank.insert(tri_rank.end(), rk.begin(), rk.end());
         }
         ref_blas_nodes += local.count();
+        sp.ref_root = (uint32_t)(ref_blas.size() / 8); sp.n_tris = n_tris;
+        ref_blas.insert(ref_blas.end(), local.nodes.begin(), local.nodes.end());
+        ref_blas_depth = std::max(ref_blas_depth, local.depth);
         if (use_sah()) { FlatBvh sah; sah_build(sah, boxes); local = std::move(sah); }
         uint32_t root = pair_convert(local, boxes, blas);     // root reference into the shared BLAS array
         blas_depth = blas.depth;
@@ -491,6 +499,9 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     Flattener fl{desc};
     std::vector<float> objs((size_t)desc->n_objects * fw::OBJ_Q * 4, 0.f);
     std::vector<Box> world(desc->n_objects), true_world(desc->n_objects);
+    std::vector<uint32_t> obj_ref_blas(desc->n_objects, 0xffffffffu);
+    std::vector<float> obj_size(desc->n_objects, 0.f);       // the exact walk's far rule: extent of an object (a mesh: of a typical triangle)
+    fw::DExact ex{};
     bool has_medium = false, has_perlin = false;
     for (uint32_t i = 0; i < desc->n_objects; i++) {
         const fw_object &o = desc->objects[i];
@@ -518,6 +529,20 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         };
         world[i] = to_world(sp.box);
         if (flags & fw::OF_GATE) true_world[i] = to_world(sp.true_box);
+        obj_ref_blas[i] = sp.ref_root;
+        {
+            const Box &tb = (flags & fw::OF_GATE) ? sp.true_box : sp.box;
+            const V3 e = tb.mx - tb.mn;
+            obj_size[i] = std::fmax(std::fabs(e.x), std::fmax(std::fabs(e.y), std::fabs(e.z)));
+            if (sp.ref_root != 0xffffffffu) {
+                obj_size[i] /= std::sqrt((float)std::max(1u, sp.n_tris));
+                if (cos_trace < 0.999f) {      // a rotated mesh: its frame is one the ill-direction test has to look at
+                    bool known = false;
+                    for (uint32_t f = 0; f < ex.n_frames && !known; f++) known = std::memcmp(ex.frames[f], rows, 36) == 0;
+                    if (!known && ex.n_frames < 4) { std::memcpy(ex.frames[ex.n_frames], rows, 36); ex.n_frames++; }
+                }
+            }
+        }
         if (o.flip_normals) flags |= fw::OF_FLIP;
         uint32_t kind = sp.kind & 0xffu, inner = (sp.kind >> 16) & 0xffu;
         if (kind == FW_SHAPE_CONSTANT_MEDIUM) has_medium = true;
@@ -542,6 +567,28 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     try { bvh_build(tlas, world); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
     std::vector<uint32_t> obj_rank = reference_ranks(tlas, desc->n_objects);
     uint32_t ref_tlas_nodes = tlas.count();
+    const std::vector<float> ref_tlas = tlas.nodes;          // the reference's own tree: what k_extend_exact walks
+    const uint32_t ref_tlas_depth = tlas.depth;
+    {   // the exact walk's flag rule (fw_device.h DExact)
+        if (!fl.tri.empty()) ex.mode |= 1u;
+        float min_size = 3.0e38f;
+        for (uint32_t i = 0; i < desc->n_objects; i++) if (obj_size[i] > 0.f) min_size = std::fmin(min_size, obj_size[i]);
+        if (min_size < 3.0e38f) {
+            Box cl{{3e38f, 3e38f, 3e38f}, {-3e38f, -3e38f, -3e38f}};
+            for (uint32_t i = 0; i < desc->n_objects; i++)
+                if (obj_size[i] > 0.f && obj_size[i] <= 16.f * min_size) cl = box_union(cl, world[i].mn.x <= world[i].mx.x ? world[i] : Box{vmin(world[i].mn, world[i].mx), vmax(world[i].mn, world[i].mx)});
+            const V3 c = box_center(cl), h = cl.mx - c;
+            const float radius = std::fmax(h.x, std::fmax(h.y, h.z));
+            ex.far_c[0] = c.x; ex.far_c[1] = c.y; ex.far_c[2] = c.z;
+            ex.far_r = std::fmax(128.f * min_size, 2.f * radius);   // noise / signal of a sphere's discriminant = 2^-23 (|o| / r)^2 <~ 1e-2 inside
+            const float pad = 2.f * min_size + 1e-3f * radius;
+            ex.box_lo[0] = cl.mn.x - pad; ex.box_lo[1] = cl.mn.y - pad; ex.box_lo[2] = cl.mn.z - pad;
+            ex.box_hi[0] = cl.mx.x + pad; ex.box_hi[1] = cl.mx.y + pad; ex.box_hi[2] = cl.mx.z + pad;
+            ex.mode |= 2u;                                          // used under use_bvh only (render_impl)
+        }
+        if (getenv("FIREWORK_NO_EXACT")) ex.mode = 0;
+        if (const char *e = getenv("FIREWORK_EXACT_ALL")) { if (atoi(e)) ex.mode |= 4u; }   // every ray takes the exact walk (parity tool / tests)
+    }
     // gate boxes: the box of each object's leaf node in the reference tree (own box for a Leaf, the union for a
     // DoubleLeaf).  In the reference an object is tested iff the ray hits that box (ancestors are supersets), which
     // matters for shapes whose own box does not enclose them (OF_GATE): they stay exactly as (in)visible as there.
@@ -673,13 +720,14 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     // one device allocation + one copy for the whole scene (12 separate hipMalloc/hipFree pairs cost up to 30 ms of a
     // one-shot render): sections are 256-byte aligned inside a host staging blob
     struct Sec { const void *src; size_t bytes, off; };
-    Sec secs[13] = {
+    Sec secs[16] = {
         {objs.data(), objs.size() * 4, 0}, {tlas_p.nodes.data(), tlas_p.nodes.size() * 4, 0}, {fl.blas.nodes.data(), fl.blas.nodes.size() * 4, 0},
         {fl.tri.data(), fl.tri.size() * 4, 0}, {fl.any_attr ? fl.tri_attr.data() : nullptr, fl.any_attr ? fl.tri_attr.size() * 4 : 0, 0},
         {fl.tri_rank.data(), fl.tri_rank.size() * 4, 0}, {obj_rank.data(), obj_rank.size() * 4, 0}, {gate.data(), gate.size() * 4, 0},
         {mats.data(), mats.size() * 4, 0}, {texs.data(), texs.size() * 4, 0}, {images.data(), images.size(), 0},
         {e.kind == FW_ENV_HDR ? e.hdr_rgb : nullptr, e.kind == FW_ENV_HDR ? (size_t)e.hdr_w * e.hdr_h * 3 * 4 : 0, 0},
-        {cull.data(), cull.size() * 4, 0}};
+        {cull.data(), cull.size() * 4, 0},
+        {ref_tlas.data(), ref_tlas.size() * 4, 0}, {fl.ref_blas.data(), fl.ref_blas.size() * 4, 0}, {obj_ref_blas.data(), obj_ref_blas.size() * 4, 0}};
     size_t total = 0;
     for (Sec &x : secs) { x.off = total; total += (x.bytes + 255) & ~(size_t)255; }
     total = std::max<size_t>(total, 256);                  // a multiple of 256: k_upload copies 16-byte words
@@ -729,6 +777,9 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.mat = (const float4 *)(base + secs[8].off); d.tex = (const float4 *)(base + secs[9].off); d.images = base + secs[10].off;
     const float *hdr_dev = (const float *)(base + secs[11].off);
     d.obj_cull = (const float4 *)(base + secs[12].off);
+    d.ref_tlas = (const float4 *)(base + secs[13].off); d.ref_blas = (const float4 *)(base + secs[14].off);
+    d.obj_ref_blas = (const uint32_t *)(base + secs[15].off);
+    sc->ex = ex; sc->ref_tlas_depth = ref_tlas_depth; sc->ref_blas_depth = fl.ref_blas_depth;
     d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_perlin = has_perlin ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
     d.prim_bits = prim_bits; d.tlas_root = tlas_root;
     d.n_hoisted = (uint32_t)hoisted.size();
@@ -847,6 +898,11 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     if (cap64 > 0x7fffffffull) return fail(FW_ERR_UNSUPPORTED, "too many path slots");
     uint32_t cap = (uint32_t)cap64;
 
+    // the exact walk: ill-conditioned mesh rays in any mode, far origins and "every ray" (FIREWORK_EXACT_ALL) under use_bvh only
+    // (the linear scan tests every object anyway: only a mesh's BLAS is walked there)
+    // (FIREWORK_FUSED=1, the one-launch-per-segment A/B kernel, has no second pass: it runs without the exact walk)
+    const bool fused_req = [] { const char *fe = getenv("FIREWORK_FUSED"); return fe && atoi(fe) != 0; }() && !(p->use_bvh && sc->d.has_mesh);
+    const uint32_t exact_mode = fused_req ? 0u : ((sc->ex.mode & 1u) | (p->use_bvh ? (sc->ex.mode & 6u) : ((sc->ex.mode & 4u) && sc->d.has_mesh ? 4u : 0u)));
     const bool tlas_refill = [] { const char *tr = getenv("FIREWORK_TLAS_REFILL"); return !(tr && atoi(tr) == 0); }();
     const bool park_meshes = p->use_bvh && sc->d.has_mesh != 0 && tlas_refill;
     int rc = FW_OK;
@@ -857,6 +913,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         need(L.hits, (size_t)cap * 8);
         need(L.sample_rad, (size_t)cap * 16);                 // indexed by home slot
         need(L.dep_bits, ((size_t)cap + 31) / 32 * 4);        // one bit per slot: "a radiance record was written here" (black environments)
+        if (exact_mode) {
+            need(L.exact_bits, ((size_t)cap + 63) / 64 * 8 + 64);        // one bit per slot: "trace this ray by the reference walk as well", + 11 per-segment list counters
+            need(L.exact_list, (size_t)cap * 4);                         // the flagged slots of one segment, dense (k_exact_scan -> k_extend_exact)
+        }
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
         if (park_meshes) {     // rays handed from k_extend_tlas_park to k_blas: 40 B per slot
             const size_t pcap = (size_t)(q.cap + 64u) * q.n_waves;     // park regions: q.cap + 64 entries per queue (DPark.stride)
@@ -918,9 +978,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     fr.pinhole0 = (cam.lens_radius == 0.f && cam.position[0] != 0.f && cam.position[1] != 0.f && cam.position[2] != 0.f &&
                    getenv("FIREWORK_NO_SHORT_RAYS") == nullptr) ? 1u : 0u;
     // 4-byte hit records where k_shade can recompute t cheaply and exactly: the linear scan over spheres, rects and Rect3d
-    fr.hit4 = (!p->use_bvh && sc->simple_shapes && getenv("FIREWORK_NO_HIT4") == nullptr && !(getenv("FIREWORK_FUSED") && atoi(getenv("FIREWORK_FUSED")))) ? 1u : 0u;
+    fr.hit4 = (!p->use_bvh && sc->simple_shapes && !exact_mode && getenv("FIREWORK_NO_HIT4") == nullptr && !(getenv("FIREWORK_FUSED") && atoi(getenv("FIREWORK_FUSED")))) ? 1u : 0u;
     const fw::DEnv &env = sc->d.env;
     fr.dep_pixel_major = (n_pix <= 65536u && getenv("FIREWORK_DEP_SLOT_MAJOR") == nullptr) || getenv("FIREWORK_DEP_PIXEL_MAJOR") != nullptr ? 1u : 0u;
+    fr.ex = sc->ex; fr.ex.mode = exact_mode; fr.ex.bits = nullptr;
     fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && getenv("FIREWORK_NO_ZERO_SKIP") == nullptr) ? 1u : 0u;
 
     // per-launch timing (FW_FLAG_TIME_KERNELS): one event after every launch on the launch's own stream; the end of
@@ -939,8 +1000,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // FIREWORK_FUSED=1: one launch per segment (k_bounce = intersect + shade in registers, 80 instead of 120 B per ray).
     // Off by default: the frame is VALU-bound, not HBM-bound, and the fused kernel's lower occupancy costs more than the
     // bytes save (cornell 62.0 vs 55.5 ms, hdri 35.5 vs 38.5 ms, 1/8-frame shares 9.2 vs 8.3 ms).  Never with parked mesh rays.
-    const char *fe = getenv("FIREWORK_FUSED");
-    const bool fused = fe && atoi(fe) != 0 && !(use_bvh && cfg.has_mesh);
+    const bool fused = fused_req;
 
     // FIREWORK_DUMP_PATH=file, one pixel x one sample: after every k_extend the path's ray, state and hit record are copied out
     // and written to `file` as 11 x 16 floats (ray_a[4] ray_b[2] state[4] hit[2] alive pad[3]) behind a header of 8 u32
@@ -968,6 +1028,12 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         fr.sample0 = first_sample + b * spp_b;
         fr.dep_bits = (uint32_t *)L.dep_bits.p;
         if (fr.skip_zero_deposits) HIPCHK(hipMemsetAsync(fr.dep_bits, 0, ((size_t)cap + 31) / 32 * 4, ls));
+        uint32_t *ex_counts = nullptr;
+        if (exact_mode) {
+            fr.ex.bits = (uint32_t *)L.exact_bits.p;
+            ex_counts = fr.ex.bits + ((size_t)cap + 63) / 64 * 2;       // behind the bitmap
+            HIPCHK(hipMemsetAsync(fr.ex.bits, 0, ((size_t)cap + 63) / 64 * 8 + 64, ls));
+        }
         fr.spp_batch = std::min(spp_b, p->samples - b * spp_b);
         uint32_t n_paths = n_pix * fr.spp_batch;
         uint32_t *totals = (uint32_t *)ws->totals.p + (size_t)b * fw::COUNT_STRIDE;
@@ -983,7 +1049,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
             if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
             else {
-                timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park); });
+                timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park);
+                               if (exact_mode) fw::launch_extend_exact(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, (uint32_t *)L.exact_list.p, ex_counts + seg); });
                 if (dump_one) {     // debug (tools/diverge.py): the one path of this call sits in slot 0 of wave 0 in every segment
                     float *r = &dump_rec[(size_t)seg * 16];
                     uint32_t alive = 0;

@@ -289,6 +289,11 @@ CONFIGS = {
 
 def config(name, width=None, height=None, samples=None):
     """(scene, renderer) for a BASELINE config, optionally at reduced size (parity tests)."""
+    if name not in CONFIGS:          # an example of the reference by its builder's name here (teapot, conics, earth, ...): its own settings
+        scene, renderer = globals()[name]()
+        s = renderer.settings
+        renderer.width(width or s["width"]).height(height or s["height"]).samples(samples or s["samples"])
+        return scene, renderer
     build, w, h, spp, bvh = CONFIGS[name]
     scene, renderer = build()
     renderer.width(width or w).height(height or h).samples(samples or spp).use_bvh(bvh)

@@ -1,0 +1,70 @@
+"""The paths on which the HIP renderer and the CPU oracle used to part ways (found by tools/diverge.py at the start of round 3,
+DESIGN.md §6), pinned one by one (-m gpu): the device traces each (pixel, sample) alone and must take the oracle's segments —
+same length, same colour — and the frames they come from must have equal ray counts per depth.
+
+  C2 cornell 512x512, pixel 112819, sample 170   a bounce ray with d.y = 0 starting ON the ceiling: t = 0/0 = NaN, which rect.rs:47-62
+                                                  accepts, after which every later hit is accepted too (`t > NaN` is false); the
+                                                  median form of the rectangle test rejected them (hit_rect: literal t interval now)
+  C3 suzanne 1280x720, five pixels                rays whose SIGNED largest direction component is tiny (util.rs:104-118 picks it as
+                                                  the shear axis of mesh.rs:147-162): shear factors of 10^4, "hits" outside the
+                                                  triangle's box, found or not depending on the walk (k_extend_exact walks them)
+  C5 part2 1920x1080, two pixels                  rays from ~1000 units away in the fog against spheres of radius 0.1: the discriminant is
+                                                  rounding noise and the reference tests the sphere behind its DoubleLeaf's box (k_extend_exact)
+  (the other eight C5 paths of that hunt started with the fog medium's log10f, ocml vs glibc by one ulp: fw_libm.h)"""
+import copy
+
+import numpy as np
+import pytest
+
+from firework_amd import _lib, scenes
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("C2_cornell_box", 512, 512, [(112819, 170)]),
+    ("C3_suzanne", 1280, 720, [(355384, 10), (360504, 9), (478225, 6), (525350, 14), (767410, 10)]),
+    ("C5_part2_all", 1920, 1080, [(148623, 0), (400990, 0), (139590, 3), (238497, 1), (442459, 3), (579166, 1), (628372, 0), (655626, 1), (900664, 1)]),
+]
+
+
+@pytest.mark.parametrize("name,w,h,paths", CASES)
+def test_formerly_diverging_paths_follow_the_oracle(oracle, monkeypatch, name, w, h, paths):
+    monkeypatch.setenv("FIREWORK_NO_ZERO_SKIP", "1")              # every path deposits: accum.w is its length in segments
+    scene, renderer = scenes.config(name, w, h, 1)
+    sd = scene.to_desc()
+    ds = _lib.DeviceScene(sd)
+    try:
+        for pixel, sample in paths:
+            segs, colour = oracle.trace_path(sd, renderer, pixel, sample)
+            length = int(segs[:, 15].sum())
+            accum = np.zeros((1, 4), np.float32)
+            ds.render_progressive(renderer, sample, accum, np.array([pixel], np.uint32))
+            assert int(accum[0, 3]) == length, (name, pixel, sample, int(accum[0, 3]), length)
+            c = np.nan_to_num(colour.astype(np.float64))
+            assert np.allclose(np.nan_to_num(accum[0, :3].astype(np.float64)), c, rtol=1e-5, atol=1e-7), (name, pixel, sample)
+    finally:
+        ds.close()
+
+
+def test_ray_counts_per_depth_equal_the_oracles_on_the_frames_they_came_from(oracle):
+    """the whole frames of the hunt (C3 at 16 spp, C5 at 4 spp; C2's 1024-spp frame is bench.py's own parity leg)"""
+    for name, spp in (("C3_suzanne", 16), ("C5_part2_all", 4)):
+        scene, renderer = scenes.config(name, samples=spp)
+        gpu, cpu = renderer.render_full(scene), oracle.render(scene, renderer)
+        assert gpu.stats["rays_per_depth"] == cpu.stats["rays_per_depth"], name
+        assert np.array_equal(gpu.rgb8, cpu.rgb8), name
+
+
+def test_every_ray_through_the_exact_walk_gives_the_same_frames(oracle, monkeypatch):
+    """FIREWORK_EXACT_ALL=1: every ray is traced by the literal reference walk (k_extend_exact) — the renderer then IS bvh.rs:115-151 —
+    and the frame equals the default one (fast walks + the flagged few) and the oracle's."""
+    for name, w, h, spp in (("C3_suzanne", 320, 180, 8), ("C5_part2_all", 240, 135, 4), ("C1_random_spheres", 200, 112, 8)):
+        scene, renderer = scenes.config(name, w, h, spp)
+        monkeypatch.delenv("FIREWORK_EXACT_ALL", raising=False)
+        fast = renderer.render_full(scene)
+        monkeypatch.setenv("FIREWORK_EXACT_ALL", "1")
+        exact = renderer.render_full(scene)
+        monkeypatch.delenv("FIREWORK_EXACT_ALL", raising=False)
+        cpu = oracle.render(scene, renderer)
+        assert exact.stats["rays_per_depth"] == cpu.stats["rays_per_depth"] == fast.stats["rays_per_depth"], name
+        assert np.array_equal(exact.linear, fast.linear) and np.array_equal(exact.rgb8, cpu.rgb8), name

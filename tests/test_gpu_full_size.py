@@ -19,54 +19,56 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RMS_GATE = 1e-3
 
 
-def full_check(oracle, scene, renderer, max_bad_pixels, name):
+def full_check(oracle, scene, renderer, name):
+    """GPU vs oracle, same seed: every path takes the same segments (ray counts per depth equal), every u8 of the image is
+    equal, and the float means agree to the rounding of a different product order (beta is multiplied left to right on the
+    device, right to left by the reference's recursion).  No pixel is tolerated: the libm-class functions are glibc's
+    (fw_libm.h) and the rays whose result depends on traversal order take the reference's own walk (k_extend_exact)."""
     gpu = renderer.render_full(scene)
     cpu = oracle.render(scene, renderer)
     g, c = np.nan_to_num(gpu.gamma.astype(np.float64)), np.nan_to_num(cpu.gamma.astype(np.float64))
     rms = float(np.sqrt(np.mean((g - c) ** 2)))
-    scale = np.maximum(np.abs(cpu.linear), 1e-3)
-    bad = int((np.abs(gpu.linear - cpu.linear) > 2e-4 * scale + 1e-6).any(axis=1).sum())
+    scale = np.maximum(np.abs(np.nan_to_num(cpu.linear)), 1e-3)
+    bad = int((np.abs(np.nan_to_num(gpu.linear) - np.nan_to_num(cpu.linear)) > 2e-5 * scale + 1e-7).any(axis=1).sum())
     d8 = int((gpu.rgb8 != cpu.rgb8).sum())
     s = renderer.settings
-    print(f"{name} {s['width']}x{s['height']}@{s['samples']}: rms={rms:.3e} bad_pixels={bad}/{g.shape[0]} u8_diffs={d8} "
+    print(f"{name} {s['width']}x{s['height']}@{s['samples']}: rms={rms:.3e} pixels beyond float noise={bad}/{g.shape[0]} u8_diffs={d8} "
           f"rays gpu={gpu.stats['rays']} cpu={cpu.stats['rays']}")
     assert rms <= RMS_GATE
-    assert bad <= max_bad_pixels
-    assert abs(gpu.stats["rays"] - cpu.stats["rays"]) <= 2 * max(1, max_bad_pixels) * s["samples"]
+    assert gpu.stats["rays_per_depth"] == cpu.stats["rays_per_depth"], name
+    assert bad == 0 and d8 == 0, (name, bad, d8)
     return gpu, cpu
 
 
 def test_c2_cornell_full_resolution(oracle):
     s, r = scenes.config("C2_cornell_box", samples=64)             # 512x512
-    gpu, cpu = full_check(oracle, s, r, 0, "C2")
-    assert gpu.stats["rays_per_depth"] == cpu.stats["rays_per_depth"]
-    assert np.array_equal(gpu.rgb8, cpu.rgb8)
+    full_check(oracle, s, r, "C2")
 
 
 def test_c1_random_spheres_full_config(oracle):
     s, r = scenes.config("C1_random_spheres")                       # 400x225 @64, the whole config
-    full_check(oracle, s, r, 40, "C1")                              # 90 000 pixels: ocml/glibc ulps in powf/sinf move a few
+    full_check(oracle, s, r, "C1")
 
 
 def test_c3_suzanne_full_resolution(oracle):
     s, r = scenes.config("C3_suzanne", samples=16)                  # 1280x720
-    full_check(oracle, s, r, 30, "C3")
+    full_check(oracle, s, r, "C3")
 
 
 def test_c4a_hdri_full_resolution_with_the_configs_4k_map(oracle):
     s, r = scenes.config("C4a_hdri_test", samples=16)               # 1024x1024, synthetic 4096x2048 f32 map (100 MB)
     assert s.environment.pixels.shape == (2048, 4096, 3)
-    full_check(oracle, s, r, 400, "C4a")                            # atan2f/asinf ulps move nearest-texel lookups on a 4k map
+    full_check(oracle, s, r, "C4a")
 
 
 def test_c4b_volume_full_resolution(oracle):
     s, r = scenes.config("C4b_volume_test", samples=16)             # 1024x1024
-    full_check(oracle, s, r, 200, "C4b")                            # log10f ulps decide free paths
+    full_check(oracle, s, r, "C4b")
 
 
 def test_c5_part2_full_resolution(oracle):
     s, r = scenes.config("C5_part2_all", samples=4)                 # 1920x1080
-    full_check(oracle, s, r, 300, "C5")
+    full_check(oracle, s, r, "C5")
 
 
 def test_teapot_yml_meshes_on_the_hip_path(oracle):
@@ -75,7 +77,7 @@ def test_teapot_yml_meshes_on_the_hip_path(oracle):
     for bvh in (True, False):
         s, r = scenes.teapot()
         r.width(480).height(270).samples(8).use_bvh(bvh)
-        full_check(oracle, s, r, 12, f"teapot bvh={bvh}")
+        full_check(oracle, s, r, f"teapot bvh={bvh}")
 
 
 def test_44k_triangle_mesh(oracle):
@@ -96,7 +98,7 @@ def test_44k_triangle_mesh(oracle):
     sc.set_environment(SkyEnv.default())
     cam = CameraSettings.default().cam_pos((0.0, 6.0, -12.0)).look_at((0.0, 1.0, 0.0)).field_of_view(40.0)
     r = Renderer.default().width(160).height(90).samples(4).use_bvh(True).camera(cam)
-    gpu, cpu = full_check(oracle, sc, r, 2, "44k mesh")
+    gpu, cpu = full_check(oracle, sc, r, "44k mesh")
     assert gpu.stats["parked_rays"] > 0                             # the mesh rays went through k_blas
 
 
@@ -114,7 +116,7 @@ def test_instanced_mesh_shares_one_blas(oracle):
     sc.set_environment(SkyEnv.default())
     cam = CameraSettings.default().cam_pos((0.0, 3.0, 12.0)).look_at((0.0, 0.0, 0.0)).field_of_view(40.0)
     r = Renderer.default().width(160).height(90).samples(4).use_bvh(True).camera(cam)
-    gpu, cpu = full_check(oracle, sc, r, 2, "instanced")
+    gpu, cpu = full_check(oracle, sc, r, "instanced")
     assert gpu.stats["blas_nodes"] == 1023                          # one suzanne BLAS (968 triangles), not four
 
 
@@ -122,7 +124,7 @@ def test_conics_and_earth_examples(oracle):
     for name, build in (("conics", scenes.conics), ("earth", scenes.earth)):
         s, r = build()
         r.width(r.settings["width"] // 2).height(r.settings["height"] // 2).samples(8)
-        full_check(oracle, s, r, 60, name)                          # atan2f/acosf/asinf ulps move texels of the image textures
+        full_check(oracle, s, r, name)
 
 
 # ---- bench.py: the multi-rank launch and the collective ------------------------------------------------------------
