@@ -10,12 +10,16 @@ N>1    : one rank per GPU over RCCL (backend "nccl").  `python bench.py --gpus N
          parent that never touches the GPU); under torch.distributed.run (WORLD_SIZE set) it is a rank itself.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  schedule       — the timed loop runs the library's own schedule (two batches in flight where that is faster); per-kernel times come
+                   from a labelled exclusive pass (one batch in flight) run right after it
   roofline       — k_shade (the kernel that moves most HBM bytes): THIS layout's algorithmic bytes (fw_stats.bytes_shade,
                    exact from the queue counters, elided zero deposits not counted) / its HIP-event time vs 8 TB/s;
                    `traffic` = PMC bytes per launch from the committed rocprofv3 passes, only when they were taken from
                    the same kernel sources as this build (else null)
   roofline_frame — the whole frame: the layout's own bytes and SURVEY §8(d)'s generic 160 B/ray formula, both over device time
-  one_shot       — fw_render_scene: conversion + BVH build + upload + render + D2H (main.rs:40-44's region), median of 3
+  one_shot       — fw_render_scene: conversion + BVH build + upload + render + D2H (main.rs:40-44's region), median of 3 warm calls
+  one_shot_cold  — the same call as the FIRST call of a fresh process (what the reference's binary times)
+  device         — clocks and a measured copy rate of the box the line was taken on
   parity         — the same frame (or a pixel lattice of it, full spp) against the CPU oracle at the same seed
   cpu_baseline   — the CPU oracle in the reference's sequential-LCG mode timed on this host's cores (bounded sample)
 """
@@ -170,6 +174,14 @@ def main():
         elapsed = float(mx[0])
         ms_gather = float(mx[6])
     total_rays, total_samples = float(vec[1]), float(vec[2])
+    rank_spread = None
+    if world > 1:      # what an imbalance would look like: per-rank rays and device time (max / mean / min over the ranks)
+        mine = torch.tensor([acc["rays"], acc["ms_render"]], dtype=torch.float64, device=vec.device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rr = [float(t[0]) for t in allr]; mm = [float(t[1]) / args.steps for t in allr]
+        rank_spread = {"rays_max_over_mean": max(rr) / (sum(rr) / world), "rays_per_rank": rr,
+                       "ms_render_max": max(mm), "ms_render_min": min(mm), "ms_render_per_rank": mm}
 
     if rank == 0:
         frame = tr.frame.cpu().numpy()
@@ -201,9 +213,21 @@ def main():
             "ms_gather_per_step": ms_gather / args.steps,
         }
         if not args.no_kernel_timing:
-            out.update(roofline_objects(acc, args, tr, renderer))
+            # The timed loop runs the library's own schedule (two batches in flight where that is faster: their kernels overlap, so
+            # their HIP-event times do too).  The roofline divides by a kernel's OWN time: a labelled exclusive pass, one batch in flight.
+            ex_acc, ex_ms = exclusive_pass(tr, keys, frames=max(2, min(5, args.steps)))
+            overlapped = (acc["ms_extend"] + acc["ms_shade"] + acc["ms_raygen"] + acc["ms_accumulate"]) > 1.05 * acc["ms_render"]
+            out["schedule"] = {"timed_loop": "two batches in flight on two streams (kernel times overlap)" if overlapped else "one batch in flight",
+                               "timed_loop_ms_per_step": ms_step, "exclusive_pass_ms_per_step": ex_ms,
+                               "exclusive_pass": f"FIREWORK_STREAMS=1, {ex_acc['frames']} frames after the timed loop: every kernel's HIP-event time is its own; "
+                                                 "roofline, roofline_frame and kernel_ms_per_step are taken from it"}
+            out.update(roofline_objects(ex_acc, args, tr, renderer, steps=ex_acc["frames"]))
+        out["device"] = device_info(device_index)
+        if world > 1:
+            out["ranks"] = rank_spread
         if world == 1 and not args.no_one_shot:
             out["one_shot"] = one_shot(scene, renderer, device_index)
+            out["one_shot_cold"] = one_shot_cold(args)
         if world == 1 and not args.no_cpu_baseline:
             cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(args, s, cores)
@@ -218,13 +242,90 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline_objects(acc, args, tr, renderer):
+def exclusive_pass(tr, keys, frames):
+    """`frames` frames with one batch in flight (FIREWORK_STREAMS=1): per-kernel HIP-event times that belong to one kernel each."""
+    prev = os.environ.get("FIREWORK_STREAMS")
+    os.environ["FIREWORK_STREAMS"] = "1"
+    try:
+        tr.render_frame()                                   # the lane's pools may have to grow: not timed
+        acc = {k: 0 for k in keys}
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            tr.render_frame()
+            for k in acc:
+                acc[k] += tr.last_stats[k]
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / frames
+    finally:
+        if prev is None:
+            del os.environ["FIREWORK_STREAMS"]
+        else:
+            os.environ["FIREWORK_STREAMS"] = prev
+    acc["frames"] = frames
+    return acc, ms
+
+
+def device_info(device_index):
+    """What the ±10 % box-to-box spread of the HBM-bound kernels should be read against: clocks as the driver reports them and a
+    measured device-to-device copy rate (1 GiB, best of 5)."""
+    import torch
+    info = {}
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        info.update(name=p.name, cus=p.multi_processor_count, hbm_gib=round(p.total_memory / 2 ** 30, 1),
+                    sclk_mhz=getattr(p, "clock_rate", 0) / 1e3, mclk_mhz=getattr(p, "memory_clock_rate", 0) / 1e3)
+        n = 1 << 28
+        a = torch.empty(n, dtype=torch.float32, device=f"cuda:{device_index}").fill_(1.0)
+        b = torch.empty_like(a)
+        best = 0.0
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); b.copy_(a); e1.record(); torch.cuda.synchronize()
+            best = max(best, 2 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        info["copy_GBps"] = round(best, 1)
+        info["copy_probe"] = "torch d2d copy of 1 GiB (read + write counted), best of 5"
+        del a, b
+    except Exception as e:
+        info["error"] = repr(e)
+    try:
+        cp = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        if cp.returncode == 0 and cp.stdout.strip().startswith("{"):
+            d = json.loads(cp.stdout)
+            card = d.get(f"card{device_index}") or next(iter(d.values()))
+            info["rocm_smi_clocks"] = {k: v for k, v in card.items() if "clk" in k.lower()}
+    except Exception:
+        pass
+    return info
+
+
+def one_shot_cold(args):
+    """The region main.rs:40-44 times, in the state the reference's binary is in when it times it: a process's FIRST call.  A
+    fresh child process renders the frame once (code-object load, pool allocation, scene creation, render, D2H) and reports it."""
+    code = ("import sys, time, json; sys.path.insert(0, %r)\n"
+            "from firework_amd import scenes, _lib\n"
+            "s, r = scenes.config(%r, %r, %r, %r); sd = s.to_desc(); _lib.load()\n"
+            "t0 = time.perf_counter(); res = _lib.render_scene(sd, r); dt = (time.perf_counter() - t0) * 1e3\n"
+            "st = res.stats\n"
+            "print(json.dumps(dict(ms_wall=dt, ms_library=st['ms_wall'], ms_scene=st['ms_scene'], ms_render=st['ms_render'], ms_d2h=st['ms_d2h'], mrays_per_s=st['rays'] / dt / 1e3)))\n"
+            % (ROOT, args.config, args.width, args.height, args.spp))
+    try:
+        cp = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        d = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
+        d["region"] = "first fw_render_scene call of a fresh process (library loaded, nothing else warm): wall = pools + code objects + scene + render + D2H"
+        return d
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def roofline_objects(acc, args, tr, renderer, steps=None):
     """Rank-0 kernel classes (every rank runs the same kernels on 1/N of the pixels).  Bytes: fw_stats.bytes_* = this
     layout's own algorithmic HBM bytes per kernel class, exact from the queue counters (fw_runtime.cpp, DESIGN.md §5);
     the deposits that k_shade elides over a black environment are counted by one extra untimed frame."""
     import glob
     res = {}
-    steps = args.steps
+    steps = steps or args.steps
     exact = tr.scene.render(renderer.count_deposits(True), pixel_ids=tr.tg.ids, out_device_ptrs=(tr.tg.local.data_ptr(), None, None))
     renderer.count_deposits(False)
     shd_bytes, ext_bytes = float(exact["bytes_shade"]), float(exact["bytes_extend"])       # per frame
@@ -285,10 +386,7 @@ def roofline_objects(acc, args, tr, renderer):
                              "survey": {"bytes": survey, "achieved": survey / dev_s / 1e9, "frac": survey / dev_s / 1e9 / HBM_PEAK_GBS,
                                         "formula": "160*rays + 24*samples (SURVEY §8d, a generic split-kernel layout) over device time"}}
     res["kernel_ms_per_step"] = {k: acc[k] / steps for k in ("ms_render", "ms_raygen", "ms_extend", "ms_shade", "ms_accumulate")}
-    lanes = int(os.environ.get("FIREWORK_STREAMS", "2" if renderer.settings["use_bvh"] else "1"))
-    if lanes > 1:
-        res["roofline"]["note"] = (f"{lanes} batches in flight on {lanes} streams (the default under use_bvh): the per-kernel HIP-event times "
-                                   "overlap in wall time, so per-kernel rates are lower bounds; FIREWORK_STREAMS=1 gives exclusive kernel times")
+    res["roofline"]["times"] = "exclusive pass (one batch in flight), see `schedule`"
     return res
 
 

@@ -92,6 +92,13 @@ def selftest_libm(fn, x, y=None, device=0):
     return out
 
 
+def build_id():
+    """sha256 of the loaded library file: identifies the kernels a checkpoint's sums were made with."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def release_workspace(device=0):
     load().fw_release_workspace(device)
 

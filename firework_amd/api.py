@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import struct
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -87,10 +88,23 @@ class Rotor3:
         `xz` by one ulp; tests/test_oracle_known_answers.py::test_rotor_constructors_match_reference_yaml)."""
         a, b = self, q
 
-        def chain(t0, t1, t2, t3):          # fma(t0, fma(t3, fma(t2, round(t1)))): products exact in f64, one rounding per step
+        def fma32(x, y, c):
+            """f32 fma(x, y, c) with ONE rounding (std::fma in include/firework.hpp): the product of two f32 is exact in f64, the
+            f64 sum is made round-to-odd with the error term of TwoSum, and an odd-rounded f64 rounds to the correct f32."""
+            p = float(x) * float(y)
+            s_ = p + float(c)
+            bb = s_ - p
+            err = (p - (s_ - bb)) + (float(c) - bb)
+            if err != 0.0 and math.isfinite(s_):
+                m = struct.unpack("<q", struct.pack("<d", s_))[0]
+                if (m & 1) == 0:                                   # even mantissa and inexact: step to the odd neighbour on the error's side
+                    s_ = math.nextafter(s_, math.inf if err > 0 else -math.inf)
+            return F32(s_)
+
+        def chain(t0, t1, t2, t3):          # fma(t0, fma(t3, fma(t2, round(t1)))): one rounding per step
             acc = F32(t1[0] * t1[1])
             for x, y in (t2, t3, t0):
-                acc = F32(float(acc) + float(x) * float(y))
+                acc = fma32(x, y, acc)
             return float(acc)
         f = lambda x: float(F32(x))
         a_s, a_xy, a_xz, a_yz, b_s, b_xy, b_xz, b_yz = (f(x) for x in (a.s, a.xy, a.xz, a.yz, b.s, b.xy, b.xz, b.yz))
@@ -685,6 +699,9 @@ class SceneDesc:
                 if isinstance(v, C.Structure):
                     feed(v)
                 elif isinstance(v, C._Pointer):
+                    if v:                                     # the array it names is hashed below: it must be one of the kept ones
+                        addr = C.cast(v, C.c_void_p).value
+                        assert any(isinstance(a, np.ndarray) and a.ctypes.data == addr for a in self._keep), f"{name}: pointer without a kept array"
                     continue
                 elif isinstance(v, C.Array):
                     h.update(bytes(v))
@@ -859,8 +876,9 @@ class Renderer:
         import os
         import sys
         cam = self._camera.to_abi()
+        # ... and on the build: an accumulation buffer written by other kernels (another ABI, other kernel sources) must not be blended in
         tag = hashlib.sha256(repr((int(s["width"]), int(s["height"]), int(s["seed"]), bool(s["use_bvh"]), sd.content_hash(),
-                                   bytes(cam))).encode()).hexdigest()
+                                   bytes(cam), int(A.FW_ABI_VERSION), int(A.FW_RNG_CTR), _lib.build_id())).encode()).hexdigest()
         if checkpoint and not str(checkpoint).endswith(".npz"):
             checkpoint = str(checkpoint) + ".npz"                       # the name np.savez would write
         if checkpoint and os.path.exists(checkpoint):

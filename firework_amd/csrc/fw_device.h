@@ -193,6 +193,7 @@ struct LaunchCfg {
     bool no_lds_tris;     // A/B switch FIREWORK_NO_LDS_TRIS   // sizes of the walked trees (pair nodes) and of the biggest mesh
     uint32_t n_defer;     // linear scan: the scene's last n_defer (1 or 2) objects are plain Rect3d boxes handled by k_extend_linear_defer; 0: k_extend_linear
     bool lds_trees;       // walk trees that fit out of LDS (k_blas_lds); FIREWORK_NO_LDS_TREES=1 switches it off
+    int shade_mode;       // k_shade: 0 everything in line (FIREWORK_NO_SHADE_DEFER=1), 1 the scene has no expensive material / environment, 2 expensive paths go through a list
     bool tlas_refill;     // refilling walks: k_extend_tlas (no meshes) / k_extend_tlas_park + k_blas (meshes); FIREWORK_TLAS_REFILL=0: the chunked k_extend_bvh
 };
 constexpr size_t LDS_TREE_LIMIT = 160 * 1024;   // the whole LDS of a CU: one workgroup of the LDS-resident walks per CU

@@ -712,29 +712,30 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
 // median-split tree, a node's items tested whenever the ray passes the NODE's box (a DoubleLeaf holds two behind one box),
 // both children always, nothing culled; the smaller t wins, a tie goes to the later item (`if lh.t < rh.t {lh} else {rh}`).
 // ref_root = first node of the mesh's tree in sc.ref_blas (child indices are relative to it).
-__device__ bool hit_mesh_exact(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
-                               float &t_out, uint32_t &tri_out) {
+constexpr int EXACT_LEVELS = 40;    // a median-split tree over N items is ceil(log2 N) deep: < 2^32 items
+__device__ __forceinline__ bool hit_mesh_exact(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
+                               uint32_t *stack, float &t_out, uint32_t &tri_out) {
     const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));      // aabb.rs:33: 1.0 / r.direction()[a]
     const TriRay tr = make_triray(r);
     const float4 *nodes = sc.ref_blas + 2 * (size_t)ref_root;
-    uint32_t stack[48]; int sp = 0;
+    int sp = 0;                                                          // stack: this lane's column of an LDS array [level][64]
     uint32_t cur = 0; bool have = false; float best = tmax; uint32_t best_tri = 0;
     for (;;) {
         const float4 lo = nodes[2 * (size_t)cur], hi = nodes[2 * (size_t)cur + 1];
         const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w), kind = A >> 30;
         if (hit_aabb(lo, hi, r.o, inv, tmin, tmax)) {
-            if (kind == 0u) { if (sp < 48) stack[sp++] = A & NODE_MASK; cur = cur + 1u; continue; }     // Branch: left = next node, right later
-            const uint32_t items[2] = {A & NODE_MASK, B};
+            if (kind == 0u) { if (sp < EXACT_LEVELS) { stack[sp * 64] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }     // Branch: left = next node, right later
             for (uint32_t k = 0; k < (kind == NODE_DOUBLE ? 2u : 1u); k++) {
-                const float4 *tp = sc.tri + 3 * (size_t)(tri_base + items[k]);
+                const uint32_t item = k ? B : (A & NODE_MASK);
+                const float4 *tp = sc.tri + 3 * (size_t)(tri_base + item);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, b0, b1, b2;
                 if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, tmin, tmax, t, b0, b1, b2))
-                    if (!have || !(best < t)) { have = true; best = t; best_tri = items[k]; }
+                    if (!have || !(best < t)) { have = true; best = t; best_tri = item; }
             }
         }
         if (sp == 0) break;
-        cur = stack[--sp];
+        sp--; cur = stack[sp * 64];
     }
     t_out = best; tri_out = best_tri;
     return have;
@@ -750,7 +751,7 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
     case 0: return hit_sphere(q3.x, r, tmin, tmax, t);
     case 1: case 2: case 3: return hit_rect_kind(kind, q3, q4, r, tmin, tmax, t);
     case 4: return hit_rect3d(q3, q4, r, tmin, tmax, t, prim);
-    case 5: if (EXACT) return hit_mesh_exact(sc, aux0, aux1, r, tmin, tmax, t, prim);
+    case 5: if (EXACT) return hit_mesh_exact(sc, aux0, aux1, r, tmin, tmax, stack_base, t, prim);
             return hit_mesh(sc, aux0, aux1, r, tmin, tmax, tmax, stack_base, t, prim);
     case 7: return hit_cone(q3.x, q3.y, r, tmin, tmax, t);
     case 8: return hit_cylinder(q3.x, q3.y, q3.z, r, tmin, tmax, t);
@@ -1766,39 +1767,39 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
 // the reference — scene.rs:137-149 (linear) or bvh.rs:115-151 over the reference's OWN trees (use_bvh) — after the fast
 // kernels; its hit records replace theirs.  One flag bit per slot, set by k_raygen / k_shade, consumed here.  The flagged
 // rays are a few per million (ill-conditioned triangle shears, noise hits from far away), so this kernel's speed does not
-// matter and it is written for clarity: private stacks, nodes from L2.
+// matter and it is written for clarity: nodes from L2, stacks in LDS.
 // With FIREWORK_EXACT_ALL=1 every ray takes it: the renderer then IS the reference's traversal (tests, tools/diverge.py).
 // ------------------------------------------------------------------------------------------------
-__device__ void closest_hit_exact(const DScene &sc, const Ray &r, const RngKey &key, int segment, bool use_bvh,
-                                  float &best_t, uint32_t &best_obj, uint32_t &best_prim) {
+__device__ __forceinline__ void closest_hit_exact(const DScene &sc, const Ray &r, const RngKey &key, int segment, bool use_bvh, uint32_t *tlas_stack,
+                                                  uint32_t *blas_stack, float &best_t, uint32_t &best_obj, uint32_t &best_prim) {
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     best_t = TMAX; best_obj = MISS; best_prim = 0;
     if (!use_bvh) {                                                  // scene.rs:137-149: in order, narrowing, a later object replaces
         for (uint32_t k = 0; k < sc.n_objects; k++) {
             const Obj o = load_obj(sc.obj, k);
             float t; uint32_t prim;
-            if (hit_object<true, true>(sc, o, k, r, TMIN, best_t, nullptr, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+            if (hit_object<true, true>(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
         }
         return;
     }
     const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
-    uint32_t stack[48]; int sp = 0;
+    int sp = 0;
     uint32_t cur = 0; bool have = false;
     for (;;) {
         const float4 lo = sc.ref_tlas[2 * (size_t)cur], hi = sc.ref_tlas[2 * (size_t)cur + 1];
         const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w), kind = A >> 30;
         if (hit_aabb(lo, hi, r.o, inv, TMIN, TMAX)) {
-            if (kind == 0u) { if (sp < 48) stack[sp++] = A & NODE_MASK; cur = cur + 1u; continue; }
-            const uint32_t items[2] = {A & NODE_MASK, B};
+            if (kind == 0u) { if (sp < EXACT_LEVELS) { tlas_stack[sp * 64] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }
             for (uint32_t k = 0; k < (kind == NODE_DOUBLE ? 2u : 1u); k++) {
-                const Obj o = load_obj(sc.obj, items[k]);
+                const uint32_t item = k ? B : (A & NODE_MASK);
+                const Obj o = load_obj(sc.obj, item);
                 float t; uint32_t prim;
-                if (hit_object<true, true>(sc, o, items[k], r, TMIN, TMAX, nullptr, key, segment, t, prim))
-                    if (!have || !(best_t < t)) { have = true; best_t = t; best_obj = items[k]; best_prim = prim; }
+                if (hit_object<true, true>(sc, o, item, r, TMIN, TMAX, blas_stack, key, segment, t, prim))
+                    if (!have || !(best_t < t)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
             }
         }
         if (sp == 0) break;
-        cur = stack[--sp];
+        sp--; cur = tlas_stack[sp * 64];
     }
 }
 // Two launches per segment: k_exact_scan reads the flag bitmap (one bit per slot, 1/256 of the queue bytes), clears it and
@@ -1816,6 +1817,10 @@ __global__ __launch_bounds__(BLOCK) void k_exact_scan(uint32_t *__restrict__ bit
 }
 __global__ __launch_bounds__(WB) void k_extend_exact(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, int segment, int use_bvh,
                                                      const uint32_t *__restrict__ list, const uint32_t *__restrict__ count) {
+    __shared__ uint32_t exact_stacks[2 * EXACT_LEVELS * 64];            // [TLAS | BLAS][level][lane] in LDS: a kernel that needs scratch memory
+                                                                          // (private stacks, calls) costs ~230 us per LAUNCH on this runtime —
+                                                                          // 110 launches were 25 of suzanne@64's 80 ms (profiles/r03f)
+    uint32_t *tlas_stack = exact_stacks + (threadIdx.x & 63u), *blas_stack = tlas_stack + EXACT_LEVELS * 64;
     const uint32_t n = *count;
     for (uint32_t k = blockIdx.x * WB + threadIdx.x; k < n; k += gridDim.x * WB) {
         const uint32_t i = list[k];
@@ -1823,7 +1828,7 @@ __global__ __launch_bounds__(WB) void k_extend_exact(DScene sc, DFrame f, DPaths
         RngKey key{0, 0, 0};
         if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
         float best_t; uint32_t best_obj, best_prim;
-        closest_hit_exact(sc, r, key, segment, use_bvh != 0, best_t, best_obj, best_prim);
+        closest_hit_exact(sc, r, key, segment, use_bvh != 0, tlas_stack, blas_stack, best_t, best_obj, best_prim);
         hits[i] = pack_hit(best_t, best_obj, best_prim, sc.prim_bits);
     }
 }
@@ -2081,6 +2086,17 @@ __device__ __forceinline__ HitInfo rebuild_hit(const DScene &sc, const Obj &o, c
 // ------------------------------------------------------------------------------------------------
 // One path at its hit (or miss): emission / environment for paths that end here (written to sample_rad, every
 // path writes exactly once), the scattered ray and throughput for those that continue (render.rs:19-31).
+// "Expensive" shading (k_shade's deferred list): what a few lanes of a chunk do while the others wait — a texture that is not a
+// constant (three sinf for a checker, 5-10 octaves of Perlin noise, an image lookup behind atan2f + asinf), the Fresnel branch
+// of a dielectric (normalise, refract, powf), a miss into an HDR map (atan2f + asinf + a gather from 100 MB).
+__device__ __forceinline__ bool expensive_shading(const DScene &sc, const float4 *objp, const float4 *matp, uint32_t hit_code) {
+    if (hit_code == MISS) return sc.env.kind == 2;
+    const uint32_t material = __float_as_uint(objp[(size_t)(hit_code >> sc.prim_bits) * OBJ_Q + 3].w);
+    const uint32_t mbits = __float_as_uint(matp[2 * material].x), mkind = mbits & 0xffu;
+    return mkind == 2u || (!(mbits & MF_TEX_CONST) && (mkind == 0u || mkind == 3u || mkind == 4u));
+}
+// CHEAP_ONLY: the caller has sent the expensive cases elsewhere (expensive_shading), their code is compiled out.
+template <bool CHEAP_ONLY = false>
 __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, const float4 *objp, const float4 *matp,
                                            const float4 *texp, const Ray &r, V3 beta, uint32_t path_id, float t_hit,
                                            uint32_t hit_code, int segment, float4 *__restrict__ sample_rad, Ray &nr, V3 &nbeta) {
@@ -2090,7 +2106,10 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
     if (obj_index == MISS) {
         // render.rs:31; ColorEnv ignores the direction, so its normalisation (sqrt + 3 divisions) is skipped
         V3 dir = sc.env.kind == 0 ? r.d : normalized(r.d);
-        rad = beta * env_sample(sc.env, dir);
+        if (CHEAP_ONLY) {      // ColorEnv or SkyEnv (environment.rs:21-26,60-67); an HdrEnvironment miss is an expensive case
+            DEnv e = sc.env; if (e.kind == 2) e.kind = 0;
+            rad = beta * env_sample(e, dir);
+        } else rad = beta * env_sample(sc.env, dir);
     } else {
         Obj o = load_obj(objp, obj_index);
         float4 m0 = matp[2 * o.material], m1 = matp[2 * o.material + 1];
@@ -2098,7 +2117,7 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
         bool need_uv = (mbits & MF_NEEDS_UV) != 0, tex_const = (mbits & MF_TEX_CONST) != 0;
         HitInfo h = rebuild_hit(sc, o, r, t_hit, hit_code & ((1u << sc.prim_bits) - 1u), need_uv, f.hit4 != 0u);
         V3 texc = mk(m1.x, m1.y, m1.z);                                      // inline ConstantTexture / Metal albedo
-        if (!tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
+        if (!CHEAP_ONLY && !tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
         if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
             rad = beta * texc;
         } else if (segment < 10) {                                             // render.rs:21
@@ -2113,7 +2132,7 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
                 V3 reflected = reflect(r.d, h.normal);
                 nr = Ray{h.point, reflected + m0.z * random_in_unit_sphere(key, segment)};
                 alive = dot(nr.d, h.normal) > 0.f; break; }
-            case 2: {                                                          // Dielectric material.rs:121-151
+            case 2: if (!CHEAP_ONLY) {                                         // Dielectric material.rs:121-151
                 float ref_idx = m0.w;
                 V3 reflected = reflect(r.d, h.normal);
                 V3 outward; float ni_over_nt, cosine;
@@ -2127,7 +2146,7 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
                     if (xi > schlick(cosine, ref_idx)) { nr = Ray{h.point, refracted}; took_refraction = true; }
                 }
                 if (!took_refraction) nr = Ray{h.point, reflected};
-                alive = true; break; }
+                alive = true; } break;
             case 4: {                                                          // Isotropic material.rs:197-204
                 nr = Ray{h.point, random_in_unit_sphere(key, segment)};
                 alive = true; break; }
@@ -2155,7 +2174,16 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
 
 extern __shared__ float4 lds_tables[];
 
-template <int LDS_TAB>   // 1: object + material + texture tables staged in LDS; 2: materials + textures only (part2: 1 409 objects are 135 KB, its 10 materials are not); 0: none
+// Round 3: the expensive materials of a chunk go to a LIST.  rocprofv3 on part2 (profiles/r02z_C5_part2_all_sq.json): k_shade ran at
+// 30 % lane utilisation and was bound by instruction issue — a handful of lanes per chunk computed five octaves of Perlin noise,
+// an earth-map lookup or a Fresnel branch while the rest waited.  MODE 2: a chunk shades its cheap paths in line (constant
+// textures, Lambertian / Metal / Isotropic / Emissive, sky or colour misses) with the expensive code compiled OUT of that loop,
+// appends the slots of the expensive ones (expensive_shading) to a wave-private list in LDS, and whenever the list holds 64 the
+// wave shades 64 expensive paths at once, every lane busy (their rays, states and hits are gathered again by slot).  Survivors
+// of both kinds are compacted into the same output queue; every result is keyed by the path's id, so the order does not matter.
+// MODE 1: the scene has no expensive material or environment at all (cornell, suzanne): the cheap loop alone, the smaller kernel.
+// MODE 0: everything in line (FIREWORK_NO_SHADE_DEFER=1: the A/B baseline, round 2's kernel).
+template <int LDS_TAB, int MODE>   // LDS_TAB 1: object + material + texture tables staged in LDS; 2: materials + textures only (part2: 1 409 objects are 135 KB, its 10 materials are not); 0: none
 // 5 waves per SIMD (96 VGPRs, no spills) instead of the compiler's 4 (114): nothing while the scattered zero deposits bound
 // the kernel (round 1), now cornell k_shade 20.55 -> 20.13 ms (four interleaved pairs), hdri 5.84 -> 5.56, suzanne 4.74 -> 4.57;
 // 6 waves (80 VGPRs) spill three registers and gain nothing more.  Requesting the queue entries TWO chunks ahead (11 more
@@ -2170,7 +2198,8 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
                                                  uint32_t n_mat, uint32_t n_tex) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     const float4 *objp = sc.obj, *matp = sc.mat, *texp = sc.tex;
-    if (sc.has_perlin) { stage_perm(); if (!LDS_TAB) __syncthreads(); }
+    __shared__ uint16_t shade_list[128];                                 // MODE 2: queue positions of the expensive paths not yet shaded (< 64 + 64)
+    if (sc.has_perlin && MODE != 1) { stage_perm(); if (!LDS_TAB) __syncthreads(); }
     if (LDS_TAB) {
         const uint32_t no = LDS_TAB == 1 ? sc.n_objects * OBJ_Q : 0u, nm = 2 * n_mat, nt = 2 * n_tex;
         if (LDS_TAB == 1) for (uint32_t k = threadIdx.x; k < no; k += WB) lds_tables[k] = sc.obj[k];
@@ -2184,36 +2213,64 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w];
     const uint32_t base = w * q.cap;
     uint32_t out_n = 0;                                                  // survivors written so far (wave-uniform)
-    // software pipeline: next chunk's ray / state / hit are in flight while the current chunk is shaded
-    float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n; float2 rb_n = make_float2(0, 0), hr_n = rb_n;
-    auto load_hit = [&](uint32_t idx) { return f.hit4 ? make_float2(0.f, __uint_as_float(reinterpret_cast<const uint32_t *>(hits)[idx])) : qld(&hits[idx]); };
-    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); st_n = load_state(in, base + lane, segment); hr_n = load_hit(base + lane); }
-    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
-        const uint32_t j = c0 + lane;
-        const uint32_t i = base + j;
-        float4 ra = ra_n, st = st_n; float2 rb = rb_n, hr = hr_n;
-        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); st_n = load_state(in, i + 64u, segment); hr_n = load_hit(i + 64u); }
-        bool alive = false;
-        Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
-        if (j < n) {
-            Ray r = make_ray(ra, rb, f, segment);
-            V3 beta = mk(st.x, st.y, st.z);
-            path_id = __float_as_uint(st.w);
-            const uint32_t hit_code = __float_as_uint(hr.y);
-            alive = shade_path(sc, f, objp, matp, texp, r, beta, path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta);
-        }
-        // ---- K7: compaction inside the wave's private queue: ballot -> mbcnt prefix -> dense stores --------
-        unsigned long long mask = __ballot(alive);
-        uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    uint32_t list_n = 0;                                                 // MODE 2: entries of shade_list (wave-uniform)
+    // ---- K7: compaction inside the wave's private queue: ballot -> mbcnt prefix -> dense stores --------
+    auto compact = [&](bool alive, const Ray &nr, V3 nbeta, uint32_t path_id) {
+        const unsigned long long mask = __ballot(alive);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (alive) {
-            uint32_t dst = base + out_n + rank;
+            const uint32_t dst = base + out_n + rank;
             qst(&out.ray_a[dst], make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x));
             qst(&out.ray_b[dst], make_float2(nr.d.y, nr.d.z));
             qst(&out.state[dst], make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id)));
             if (f.ex.mode && needs_exact(f.ex, nr.o.x, nr.o.y, nr.o.z, nr.d.x, nr.d.y, nr.d.z)) flag_exact(f.ex, dst);
         }
         out_n += (uint32_t)__popcll(mask);
+    };
+    auto load_hit = [&](uint32_t idx) { return f.hit4 ? make_float2(0.f, __uint_as_float(reinterpret_cast<const uint32_t *>(hits)[idx])) : qld(&hits[idx]); };
+    // MODE 2: the last `take` listed paths, one per lane, with the full shading code
+    auto run_list = [&](uint32_t take) {
+        bool alive = false;
+        Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
+        if (lane < take) {
+            const uint32_t i = base + shade_list[list_n - take + lane];
+            const float4 ra = qld(&in.ray_a[i]), st = load_state(in, i, segment); const float2 rb = load_ray_b(in, i, f, segment), hr = load_hit(i);
+            path_id = __float_as_uint(st.w);
+            alive = shade_path<false>(sc, f, objp, matp, texp, make_ray(ra, rb, f, segment), mk(st.x, st.y, st.z), path_id, hr.x, __float_as_uint(hr.y), segment, sample_rad, nr, nbeta);
+        }
+        list_n -= take;
+        compact(alive, nr, nbeta, path_id);
+    };
+    // software pipeline: next chunk's ray / state / hit are in flight while the current chunk is shaded
+    float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n; float2 rb_n = make_float2(0, 0), hr_n = rb_n;
+    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); st_n = load_state(in, base + lane, segment); hr_n = load_hit(base + lane); }
+    for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        const uint32_t j = c0 + lane;
+        const uint32_t i = base + j;
+        float4 ra = ra_n, st = st_n; float2 rb = rb_n, hr = hr_n;
+        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); st_n = load_state(in, i + 64u, segment); hr_n = load_hit(i + 64u); }
+        bool alive = false, later = false;
+        Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
+        if (j < n) {
+            Ray r = make_ray(ra, rb, f, segment);
+            V3 beta = mk(st.x, st.y, st.z);
+            path_id = __float_as_uint(st.w);
+            const uint32_t hit_code = __float_as_uint(hr.y);
+            if (MODE == 2 && expensive_shading(sc, objp, matp, hit_code)) later = true;
+            else alive = shade_path<MODE != 0>(sc, f, objp, matp, texp, r, beta, path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta);
+        }
+        compact(alive, nr, nbeta, path_id);
+        if (MODE == 2) {
+            const unsigned long long lm = __ballot(later);
+            if (lm) {
+                const uint32_t lr = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                if (later) shade_list[list_n + lr] = (uint16_t)j;
+                list_n += (uint32_t)__popcll(lm);
+                if (list_n >= 64u) run_list(64u);
+            }
+        }
     }
+    if (MODE == 2) while (list_n) run_list(min(list_n, 64u));
     if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
 }
 
@@ -2569,13 +2626,17 @@ void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths 
                   float4 *sample_rad, int segment) {
     size_t tab = ((size_t)sc.n_objects * OBJ_Q + 2 * (size_t)c.n_mat + 2 * (size_t)c.n_tex) * sizeof(float4);
     const size_t tab_mt = (2 * (size_t)c.n_mat + 2 * (size_t)c.n_tex) * sizeof(float4);
-    if (c.lds_tables && tab <= LDS_TABLE_LIMIT)
-        hipLaunchKernelGGL(k_shade<1>, wave_grid(c), dim3(WB), tab, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
-    else if (c.lds_tables && tab_mt <= LDS_TABLE_LIMIT)   // the two dependent fetches behind the object record come from LDS (part2 k_shade 6.7 -> 6.55 ms;
-        // a leaner per-kind object fetch on top — 3 loads instead of 6 for an unrotated sphere — did not pay: 6.8 ms)
-        hipLaunchKernelGGL(k_shade<2>, wave_grid(c), dim3(WB), tab_mt, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
-    else
-        hipLaunchKernelGGL(k_shade<0>, wave_grid(c), dim3(WB), 0, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex);
+    // table mode: everything in LDS | materials + textures only (the two dependent fetches behind the object record: part2 k_shade
+    // 6.7 -> 6.55 ms; a leaner per-kind object fetch on top — 3 loads instead of 6 for an unrotated sphere — did not pay: 6.8 ms) | none
+    const int lt = (c.lds_tables && tab <= LDS_TABLE_LIMIT) ? 1 : ((c.lds_tables && tab_mt <= LDS_TABLE_LIMIT) ? 2 : 0);
+    const size_t lds = lt == 1 ? tab : (lt == 2 ? tab_mt : 0);
+    // shading mode (k_shade): 0 everything in line | 1 the scene has nothing expensive | 2 expensive paths through the list
+    const int mode = c.shade_mode;
+#define FW_SHADE(L, M) hipLaunchKernelGGL((k_shade<L, M>), wave_grid(c), dim3(WB), lds, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex)
+#define FW_SHADE_L(L) do { if (mode == 2) FW_SHADE(L, 2); else if (mode == 1) FW_SHADE(L, 1); else FW_SHADE(L, 0); } while (0)
+    if (lt == 1) FW_SHADE_L(1); else if (lt == 2) FW_SHADE_L(2); else FW_SHADE_L(0);
+#undef FW_SHADE_L
+#undef FW_SHADE
 }
 void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, float4 *sample_rad,
                    int segment, bool use_bvh) {

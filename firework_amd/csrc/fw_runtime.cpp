@@ -289,9 +289,12 @@ struct Workspace {
     void *staging = nullptr; size_t staging_bytes = 0;  // pinned host memory the scene blob is assembled in (k_upload reads it)
     void *host_out = nullptr; size_t host_out_bytes = 0; // pinned host memory the counters and output frames are copied into
     hipEvent_t ev_upload = nullptr;       // after the latest scene upload on this device: renders wait for it in stream order
+    hipStream_t upload_stream = nullptr;  // the upload kernel's own non-blocking stream: a launch on the legacy NULL stream would
+                                          // synchronise with every blocking stream of the process (torch's default stream included)
     void release() {
         if (ev_d2h) { (void)hipEventDestroy(ev_d2h); ev_d2h = nullptr; }
         if (ev_upload) { (void)hipEventSynchronize(ev_upload); (void)hipEventDestroy(ev_upload); ev_upload = nullptr; }
+        if (upload_stream) { (void)hipStreamDestroy(upload_stream); upload_stream = nullptr; }
         if (staging) { (void)hipHostFree(staging); staging = nullptr; staging_bytes = 0; }
         if (host_out) { (void)hipHostFree(host_out); host_out = nullptr; host_out_bytes = 0; }
         tile_ids.release(); tile_w = tile_h = 0;
@@ -327,6 +330,7 @@ struct fw_scene {
     uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mat = 0, n_tex = 0;
     uint32_t blas_pair_nodes = 0, tlas_pair_nodes = 0, max_tris = 0, n_tris = 0;
     uint32_t n_defer = 0;
+    bool has_expensive = false;   // some material is a dielectric or carries a non-constant texture, or the environment is an HDR map (k_shade's list)
     bool simple_shapes = false;   // every object is a sphere, an axis-aligned rect or a Rect3d (no medium, mesh, cone, cylinder, disk)
     bool hdr_env = false;
     fw::DExact ex{};              // flag rule of the exact walk (bits pointer is per render)
@@ -762,9 +766,10 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     rc = sc->data.alloc(total);
     const double tr_alloc = ms_since(tr2);
     const auto tr3 = now();
+    if (!rc && !ws->upload_stream && hipStreamCreateWithFlags(&ws->upload_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(FW_ERR_HIP, "upload stream creation failed");
     if (!rc) {
-        fw::launch_upload(nullptr, blob, sc->data.p, total);
-        if (hipEventRecord(ws->ev_upload, nullptr) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(FW_ERR_HIP, "scene upload failed");
+        fw::launch_upload(ws->upload_stream, blob, sc->data.p, total);
+        if (hipEventRecord(ws->ev_upload, ws->upload_stream) != hipSuccess || hipGetLastError() != hipSuccess) rc = fail(FW_ERR_HIP, "scene upload failed");
     }
     if (trace) fprintf(stderr, "[firework] scene_create: build %.2f ms, blob %.2f ms (%zu B), alloc %.2f ms (%s), upload launch %.2f ms\n",
                        tr_build, tr_blob, total, tr_alloc, reused ? "cached" : "hipMalloc", ms_since(tr3));
@@ -790,6 +795,12 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.env.horizon[0] = e.horizon.x; d.env.horizon[1] = e.horizon.y; d.env.horizon[2] = e.horizon.z;
     d.env.hdr = hdr_dev; d.env.hdr_w = e.hdr_w; d.env.hdr_h = e.hdr_h;
     sc->hdr_env = e.kind == FW_ENV_HDR;
+    sc->has_expensive = sc->hdr_env;
+    for (uint32_t i = 0; i < desc->n_materials; i++) {
+        uint32_t mb; std::memcpy(&mb, &mats[(size_t)i * 8], 4);
+        const uint32_t mk = mb & 0xffu;
+        if (mk == (uint32_t)FW_MAT_DIELECTRIC || (!(mb & fw::MF_TEX_CONST) && (mk == (uint32_t)FW_MAT_LAMBERTIAN || mk == (uint32_t)FW_MAT_EMISSIVE || mk == (uint32_t)FW_MAT_ISOTROPIC))) sc->has_expensive = true;
+    }
     sc->simple_shapes = true;
     for (uint32_t i = 0; i < desc->n_objects; i++) { uint32_t kf; std::memcpy(&kf, &objs[(size_t)i * fw::OBJ_Q * 4 + 3], 4); if ((kf & 0xffu) > 4u) sc->simple_shapes = false; }
     // the trailing plain boxes of a linear scene (k_extend_linear_defer): at most two, no media or meshes anywhere in the scene
@@ -866,7 +877,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // The linear scan stays at one batch in flight: cornell gains 4-5 % (42.2 -> 40.3 ms), hdri and volume lose 1-3 %
     // (both of their kernels wait for HBM), and with one lane every kernel's HIP-event time is its own — what bench.py's
     // roofline object divides by.  FIREWORK_STREAMS=n overrides.  Results do not depend on n (batches accumulate in order).
-    int n_lanes = p->use_bvh ? 2 : 1;
+    // Round 3: a linear scene whose scan runs the box lists (k_extend_linear_defer: cornell) takes two lanes as well — its scan is
+    // bound by instruction issue, its k_shade by HBM, and they overlap (42.2 -> 40.3 ms in round 2's A/B); per-kernel times for
+    // the roofline come from an exclusive pass (FIREWORK_STREAMS=1) that bench.py runs next to the timed loop.
+    int n_lanes = (p->use_bvh || sc->n_defer > 0) ? 2 : 1;
     if (const char *e = getenv("FIREWORK_STREAMS")) { int v = atoi(e); if (v >= 1) n_lanes = std::min(v, (int)Workspace::MAX_LANES); }
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, p->samples);
     uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch() / (uint32_t)n_lanes;
@@ -966,6 +980,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.no_lds_tris = getenv("FIREWORK_NO_LDS_TRIS") != nullptr;
     cfg.n_defer = (!p->use_bvh && getenv("FIREWORK_NO_DEFER") == nullptr) ? sc->n_defer : 0u;
     cfg.lds_trees = getenv("FIREWORK_NO_LDS_TREES") == nullptr;
+    // k_shade's list entries are 16-bit queue positions: longer queues (cap > 65536: never with the default geometry) shade in line
+    cfg.shade_mode = (getenv("FIREWORK_NO_SHADE_DEFER") != nullptr || q.cap > 65536u) ? 0 : (sc->has_expensive ? 2 : 1);
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
@@ -980,7 +996,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // 4-byte hit records where k_shade can recompute t cheaply and exactly: the linear scan over spheres, rects and Rect3d
     fr.hit4 = (!p->use_bvh && sc->simple_shapes && !exact_mode && getenv("FIREWORK_NO_HIT4") == nullptr && !(getenv("FIREWORK_FUSED") && atoi(getenv("FIREWORK_FUSED")))) ? 1u : 0u;
     const fw::DEnv &env = sc->d.env;
-    fr.dep_pixel_major = (n_pix <= 65536u && getenv("FIREWORK_DEP_SLOT_MAJOR") == nullptr) || getenv("FIREWORK_DEP_PIXEL_MAJOR") != nullptr ? 1u : 0u;
+    // (pixel-major bits need the sample index of a path from a float quotient that is exact only while spp_batch < 2^21: dep_bit_of)
+    fr.dep_pixel_major = (((n_pix <= 65536u && getenv("FIREWORK_DEP_SLOT_MAJOR") == nullptr) || getenv("FIREWORK_DEP_PIXEL_MAJOR") != nullptr) && spp_b < (1u << 21)) ? 1u : 0u;
     fr.ex = sc->ex; fr.ex.mode = exact_mode; fr.ex.bits = nullptr;
     fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && getenv("FIREWORK_NO_ZERO_SKIP") == nullptr) ? 1u : 0u;
 
@@ -1310,16 +1327,38 @@ int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *par
         const size_t b8 = rgb8 ? n_total * 3 : 0, bg = gamma_rgb ? n_total * 12 : 0, bl = linear_rgb ? n_total * 12 : 0;
         const size_t o_ids = 0, o_g8 = al(n_total * 4), o_gg = o_g8 + al(b8), o_gl = o_gg + al(bg), o_f8 = o_gl + al(bl), o_fg = o_f8 + al(b8),
                      o_fl = o_fg + al(bg), dev_bytes = o_fl + al(bl) + 256;
-        DevBuf gather;
+        struct GatherBuf : DevBuf { int dev; explicit GatherBuf(int d) : dev(d) {} ~GatherBuf() { if (p) { (void)hipSetDevice(dev); release(); } } };
+        GatherBuf gather(dev0);                                    // released on every way out of this function, exceptions included
         int grc = gather.alloc(dev_bytes);
         if (grc) return grc;
         uint8_t *gb = (uint8_t *)gather.p;
         {
             std::vector<uint32_t> all_ids; all_ids.reserve(n_total);
             for (int r = 0; r < N; r++) all_ids.insert(all_ids.end(), ids[r].begin(), ids[r].end());
-            if (hipMemcpy(gb + o_ids, all_ids.data(), n_total * 4, hipMemcpyHostToDevice) != hipSuccess) { gather.release(); return fail(FW_ERR_HIP, "tile id upload failed"); }
+            if (hipMemcpy(gb + o_ids, all_ids.data(), n_total * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(FW_ERR_HIP, "tile id upload failed");
         }
+        // Peer access to the first device, asked for once per pair (hipMemcpyPeer works without it, staged through the host by the
+        // runtime; with it the copy goes over the xGMI link).  Where a pair has no peer path the tiles are staged through pinned
+        // host memory here, and fw_last_error() says so after a successful call.
+        std::vector<char> peer_ok(N, 1);
+        std::string peer_note;
+        for (int r = 0; r < N; r++) {
+            if (devices[r] == dev0) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[r], dev0) != hipSuccess) can = 0;
+            if (can) {
+                (void)hipSetDevice(devices[r]);
+                const hipError_t pe = hipDeviceEnablePeerAccess(dev0, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) can = 0;
+                (void)hipGetLastError();
+            }
+            if (!can) { peer_ok[r] = 0; peer_note += (peer_note.empty() ? "no peer access to device " : ", ") + std::to_string(devices[r]); }
+        }
+        (void)hipSetDevice(dev0);
+        if (!peer_note.empty()) peer_note = peer_note + " from device " + std::to_string(dev0) + ": those tiles were staged through host memory";
         std::vector<std::thread> threads;
+        struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{threads};   // a failed emplace_back must not destroy joinable threads
+        threads.reserve((size_t)N);
         for (int r = 0; r < N; r++) threads.emplace_back([&, r] {
             Part &pt = parts[r];
             const size_t n = ids[r].size();
@@ -1342,7 +1381,17 @@ int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *par
                     pt.rc = fw_render(sc, &p, rgb8 ? pb + q8 : nullptr, gamma_rgb ? (float *)(pb + qg) : nullptr, linear_rgb ? (float *)(pb + ql) : nullptr, &pt.st);
                     if (pt.rc) pt.err = g_last_error;
                     auto peer = [&](size_t dst_off, size_t src_off, size_t bytes) {
-                        if (!pt.rc && bytes && hipMemcpyPeer(gb + dst_off, dev0, pb + src_off, devices[r], bytes) != hipSuccess) { pt.rc = FW_ERR_HIP; pt.err = "hipMemcpyPeer of a device's tiles failed"; }
+                        if (pt.rc || !bytes) return;
+                        if (peer_ok[r]) {
+                            if (hipMemcpyPeer(gb + dst_off, dev0, pb + src_off, devices[r], bytes) != hipSuccess) { pt.rc = FW_ERR_HIP; pt.err = "hipMemcpyPeer of a device's tiles failed"; }
+                            return;
+                        }
+                        void *host = nullptr;                            // no peer path: device -> pinned host -> first device
+                        if (hipHostMalloc(&host, bytes, hipHostMallocDefault) != hipSuccess) { pt.rc = FW_ERR_OOM; pt.err = "pinned staging for a device's tiles failed"; return; }
+                        hipError_t e = hipMemcpy(host, pb + src_off, bytes, hipMemcpyDeviceToHost);
+                        if (e == hipSuccess) { (void)hipSetDevice(dev0); e = hipMemcpy(gb + dst_off, host, bytes, hipMemcpyHostToDevice); (void)hipSetDevice(devices[r]); }
+                        (void)hipHostFree(host);
+                        if (e != hipSuccess) { pt.rc = FW_ERR_HIP; pt.err = "host-staged copy of a device's tiles failed"; }
                     };
                     peer(o_g8 + first[r] * 3, q8, p8); peer(o_gg + first[r] * 12, qg, pg); peer(o_gl + first[r] * 12, ql, pl);
                 } else pt.err = g_last_error;
@@ -1351,17 +1400,17 @@ int fw_render_scene_tiled(const fw_scene_desc *desc, const fw_render_params *par
             } catch (...) { pt.rc = FW_ERR_OOM; pt.err = "host allocation failed in a tile worker"; }
         });
         for (auto &t : threads) t.join();
-        for (int r = 0; r < N; r++) if (parts[r].rc) { (void)hipSetDevice(dev0); gather.release(); return fail(parts[r].rc, parts[r].err); }
+        for (int r = 0; r < N; r++) if (parts[r].rc) return fail(parts[r].rc, parts[r].err);
         // the one scatter and the one device -> host transfer
         (void)hipSetDevice(dev0);
         fw::launch_scatter_tiles(nullptr, (const uint32_t *)(gb + o_ids), (uint32_t)n_total, rgb8 ? gb + o_g8 : nullptr, gamma_rgb ? (const float *)(gb + o_gg) : nullptr,
                                  linear_rgb ? (const float *)(gb + o_gl) : nullptr, gb + o_f8, (float *)(gb + o_fg), (float *)(gb + o_fl));
-        hipError_t ce = hipSuccess;
+        hipError_t ce = hipGetLastError();                          // the scatter launch itself
         if (rgb8 && ce == hipSuccess) ce = hipMemcpy(rgb8, gb + o_f8, b8, hipMemcpyDeviceToHost);
         if (gamma_rgb && ce == hipSuccess) ce = hipMemcpy(gamma_rgb, gb + o_fg, bg, hipMemcpyDeviceToHost);
         if (linear_rgb && ce == hipSuccess) ce = hipMemcpy(linear_rgb, gb + o_fl, bl, hipMemcpyDeviceToHost);
-        gather.release();
         if (ce != hipSuccess) return fail(FW_ERR_HIP, hipGetErrorString(ce));
+        if (!peer_note.empty()) g_last_error = peer_note;          // informational: the call succeeded
         if (stats) std::memset(stats, 0, sizeof *stats);
         for (int r = 0; r < N; r++) {
             const Part &pt = parts[r];

@@ -214,7 +214,7 @@ typedef struct fw_stats {
     uint64_t rays;                           /* root.hit() calls = path segments (render.rs:19)    */
     uint64_t rays_per_depth[FW_MAX_SEGMENTS];
     uint64_t algorithmic_bytes;              /* 160*rays + 24*samples (+12*env misses for HDR), SURVEY §8(d) */
-    double ms_scene;                         /* host: flatten + BVH build + upload (one-shot call only)      */
+    double ms_scene;                         /* host: flatten + BVH build + LAUNCH of the upload (one-shot call only); the upload kernel itself is asynchronous and the render that follows waits for it, so its time is part of ms_render */
     double ms_render;                        /* device: first launch to last, HIP events on the launch stream */
     double ms_raygen, ms_extend, ms_shade, ms_accumulate; /* per-kernel-class device time (HIP events) */
     uint32_t n_extend_launches, n_shade_launches, n_batches;  /* FIREWORK_FUSED=1: no extend launches, the fused

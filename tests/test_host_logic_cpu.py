@@ -67,3 +67,25 @@ def test_objects_that_share_a_shape_share_its_record():
     d = sc.to_desc()
     assert d.desc.n_objects == 3 and d.desc.n_shapes == 1
     assert [d.objects[i].shape for i in range(3)] == [0, 0, 0]
+
+
+def test_python_and_cpp_rotor_products_agree_bit_for_bit(tmp_path):
+    """firework_amd/api.py emulates the f32 fma chain of the rotor product (round-to-odd in f64, then one rounding to f32);
+    include/firework.hpp uses std::fma.  10 000 random rotor pairs must give the same bits in both hosts."""
+    import subprocess
+    import numpy as np
+    from firework_amd.api import Rotor3
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "rotor.cpp"
+    src.write_text('#include "firework.hpp"\n#include <cstdio>\nint main(int c, char **v) { FILE *f = fopen(v[1], "rb"), *o = fopen(v[2], "wb"); float a[8];\n'
+                   '  while (fread(a, 4, 8, f) == 8) { firework::Rotor3 x{a[0], a[1], a[2], a[3]}, y{a[4], a[5], a[6], a[7]}; firework::Rotor3 r = x * y; float q[4] = {r.s, r.xy, r.xz, r.yz}; fwrite(q, 4, 4, o); }\n'
+                   '  fclose(f); fclose(o); return 0; }\n')
+    exe = tmp_path / "rotor"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
+    rng = np.random.default_rng(11)
+    ab = (rng.standard_normal((10000, 8)) * np.exp(rng.uniform(-3, 3, (10000, 8)))).astype(np.float32)
+    (tmp_path / "in.bin").write_bytes(ab.tobytes())
+    subprocess.check_call([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")])
+    cpp = np.frombuffer((tmp_path / "out.bin").read_bytes(), np.float32).reshape(-1, 4)
+    py = np.array([[r.s, r.xy, r.xz, r.yz] for r in (Rotor3(*map(float, p[:4])) * Rotor3(*map(float, p[4:])) for p in ab)], np.float32)
+    assert np.array_equal(py.view(np.uint32), cpp.view(np.uint32))

@@ -1,7 +1,16 @@
-# All BASELINE configs at full size on one GPU (parity cases; only C2 is the bench line).
+# All BASELINE configs at full size on one GPU (parity cases; only C2 is the bench line): one JSON line per config with the frame
+# time of the library's own schedule, the per-kernel times of the exclusive pass and the roofline objects (profiles/*_configs_full.jsonl).
 R=$PWD
 run() {
-  python3 $R/bench.py --config $1 --steps $2 --warmup $3 --no-cpu-baseline --no-one-shot 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('kernel_ms_per_step',{}); print(json.dumps({'config': d['config']['workload'], 'Mrays/s': round(d['value']), 'Msamples/s': round(d['msamples_per_s']), 'ms_per_frame': round(d['ms_per_step'],1), 'rays_per_sample': round(d['rays_per_sample'],2), 'ms_extend': round(k.get('ms_extend',0),1), 'ms_shade': round(k.get('ms_shade',0),1)}))"
+  timeout -k 10 900 python3 $R/bench.py --config $1 --steps $2 --warmup $3 --no-cpu-baseline --no-one-shot 2>/dev/null | tail -1 | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('kernel_ms_per_step',{}); r=d.get('roofline',{}); o=r.get('other_kernel',{})
+print(json.dumps({'config': d['config']['workload'], 'Mrays/s': round(d['value']), 'Msamples/s': round(d['msamples_per_s']), 'ms_per_frame': round(d['ms_per_step'],2),
+  'rays_per_sample': round(d['rays_per_sample'],2), 'schedule': d.get('schedule',{}).get('timed_loop'), 'exclusive_ms_per_frame': round(d.get('schedule',{}).get('exclusive_pass_ms_per_step',0),2),
+  'exclusive_kernel_ms': {a: round(b,2) for a,b in k.items()},
+  'roofline': {'kernel': r.get('kernel'), 'bound': r.get('bound'), 'achieved_GBps': round(r.get('achieved',0)), 'frac_of_8TBps': round(r.get('frac',0),3), 'bytes_per_ray': round(r.get('bytes_per_ray',0),1), 'avg_launch_us': round(r.get('avg_launch_us',0),1)},
+  'extend': {'bound': o.get('bound'), 'achieved_GBps': round(o.get('achieved',0)), 'frac_of_8TBps': round(o.get('frac_hbm',0),3), 'avg_launch_us': round(o.get('avg_launch_us',0),1)},
+  'roofline_frame_layout_frac': round(d.get('roofline_frame',{}).get('layout',{}).get('frac',0),3), 'device': {a: b for a,b in d.get('device',{}).items() if a in ('name','sclk_mhz','mclk_mhz','copy_GBps')}}))"
 }
 run C1_random_spheres 3 1
 run C2_cornell_box 3 1

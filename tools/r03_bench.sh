@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 3: suite, the bench line (two lanes + exclusive pass), lane A/B on cornell, the Infinity-Cache batch experiment, all configs at full size
+set -o pipefail
+OUT=$PWD/gpurun_out/$1; mkdir -p $OUT
+timeout -k 10 500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest.log
+timeout -k 10 400 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; python3 -c "
+import json; d=json.load(open('$OUT/bench.json')); print({k: d[k] for k in ('value','ms_per_step','schedule','device','one_shot_cold')}); print(d['roofline']['frac'], d['roofline']['avg_launch_us'], d['kernel_ms_per_step'], d['parity']['rays_equal'], d['parity']['u8_diffs'])"
+echo "== cornell lanes A/B"
+for i in 1 2 3; do for n in 1 2; do FIREWORK_STREAMS=$n timeout -k 10 200 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-one-shot --no-kernel-timing 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('streams=$n ms', round(d['ms_per_step'],2))"; done; done 2>&1 | tee $OUT/lanes_ab.txt
+echo "== Infinity-Cache-sized batches (paths per batch x streams)"
+for ppb in 2097152 4194304 8388608 33554432; do for n in 2 4; do FIREWORK_STREAMS=$n FIREWORK_PATHS_PER_BATCH=$ppb timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-shot --no-kernel-timing 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ppb=$ppb streams=$n ms', round(d['ms_per_step'],2))"; done; done 2>&1 | tee $OUT/mall_batches.txt
+echo "== all configs"; bash tools/configs.sh 2>&1 | tee $OUT/configs_full.jsonl
