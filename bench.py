@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-KERNEL_SOURCES = ("firework_amd/csrc/fw_kernels.hip", "firework_amd/csrc/fw_runtime.cpp", "firework_amd/csrc/fw_device.h", "Makefile")
+KERNEL_SOURCES = ("firework_amd/csrc/fw_kernels.hip", "firework_amd/csrc/fw_runtime.cpp", "firework_amd/csrc/fw_device.h", "firework_amd/csrc/fw_libm.h", "Makefile")
 
 
 def kernel_source_sha():
@@ -246,16 +246,18 @@ def exclusive_pass(tr, keys, frames):
     """`frames` frames with one batch in flight (FIREWORK_STREAMS=1): per-kernel HIP-event times that belong to one kernel each."""
     prev = os.environ.get("FIREWORK_STREAMS")
     os.environ["FIREWORK_STREAMS"] = "1"
+    def frame():          # this rank's share, no collective (only rank 0 runs the exclusive pass)
+        return tr.scene.render(tr.renderer, pixel_ids=tr.tg.ids, out_device_ptrs=(tr.tg.local.data_ptr(), None, None))
     try:
-        tr.render_frame()                                   # the lane's pools may have to grow: not timed
+        frame()                                             # the lane's pools may have to grow: not timed
         acc = {k: 0 for k in keys}
         import torch
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(frames):
-            tr.render_frame()
+            st = frame()
             for k in acc:
-                acc[k] += tr.last_stats[k]
+                acc[k] += st[k]
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / frames
     finally:

@@ -254,7 +254,24 @@ __device__ __forceinline__ bool needs_exact(const DExact &ex, float ox, float oy
     }
     return false;
 }
-__device__ __forceinline__ void flag_exact(const DExact &ex, uint32_t slot) { atomicOr(&ex.bits[slot >> 5], 1u << (slot & 31u)); }
+// The flagged paths of one wave-chunk leave the wavefront: their slot's bit is set (k_shade will skip the slot) and path state +
+// ray go to the batch's list for k_exact_paths.  Called by every lane of the wave (fl = false where there is nothing to send):
+// one device-wide atomic per wave and chunk that flags anything.
+__device__ __forceinline__ void send_exact(const DExact &ex, bool fl, uint32_t slot, V3 o, V3 d, V3 beta, uint32_t home, int segment) {
+    const unsigned long long m = __ballot(fl);
+    if (!m) return;
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)m) - 1u;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    uint32_t at = 0;
+    if (lane == leader) at = atomicAdd(ex.list_count, (uint32_t)__popcll(m));
+    at = (uint32_t)__shfl((int)at, (int)leader) + rank;
+    if (fl && at < ex.list_cap) {
+        atomicOr(&ex.bits[slot >> 5], 1u << (slot & 31u));
+        float4 *e = ex.list + 3 * (size_t)at;
+        e[0] = make_float4(o.x, o.y, o.z, d.x); e[1] = make_float4(d.y, d.z, beta.x, beta.y);
+        e[2] = make_float4(beta.z, __uint_as_float(home), __uint_as_float((uint32_t)segment), 0.f);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // K1  ray generation
@@ -328,17 +345,19 @@ __global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out
         uint32_t id0 = chunk * (q.n_waves * 64u) + w * 64u;
         if (id0 >= n_paths) break;
         uint32_t i = id0 + lane;
+        const uint32_t slot = w * q.cap + chunk * 64u + lane;
+        bool fl = false; V3 o = mk(0, 0, 0), d = o;
         if (i < n_paths) {
             const Ray r = camera_ray(cam, f, key_of_linear(f, i));
-            const V3 o = r.o, d = r.d;
-            uint32_t slot = w * q.cap + chunk * 64u + lane;
+            o = r.o; d = r.d;
             if (f.pinhole0) qst(&out.ray_a[slot], make_float4(d.x, d.y, d.z, 0.f));
             else {
                 qst(&out.ray_a[slot], make_float4(o.x, o.y, o.z, d.x));
                 qst(&out.ray_b[slot], make_float2(d.y, d.z));
             }
-            if (f.ex.mode && needs_exact(f.ex, o.x, o.y, o.z, d.x, d.y, d.z)) flag_exact(f.ex, slot);
+            fl = f.ex.mode && needs_exact(f.ex, o.x, o.y, o.z, d.x, d.y, d.z);
         }
+        if (f.ex.mode) send_exact(f.ex, fl, slot, o, d, mk(1.f, 1.f, 1.f), slot, 0);     // a camera path: throughput 1, home slot = its slot
         produced += min(64u, n_paths - id0);
     }
     if (lane == 0) q.wcount[w] = produced;                                    // segment 0 queue length of this wave
@@ -708,41 +727,54 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
     return have;
 }
 
-// The literal mesh walk of the reference (bvh.rs:115-151 over mesh.rs's Triangle items) for k_extend_exact: the mesh's own
+// The literal mesh walk of the reference (bvh.rs:115-151 over mesh.rs's Triangle items) for k_exact_paths: the mesh's own
 // median-split tree, a node's items tested whenever the ray passes the NODE's box (a DoubleLeaf holds two behind one box),
 // both children always, nothing culled; the smaller t wins, a tie goes to the later item (`if lh.t < rh.t {lh} else {rh}`).
 // ref_root = first node of the mesh's tree in sc.ref_blas (child indices are relative to it).
 constexpr int EXACT_LEVELS = 40;    // a median-split tree over N items is ceil(log2 N) deep: < 2^32 items
+constexpr int EXACT_WB = 256;       // threads per workgroup of k_exact_paths: its stacks are [level][EXACT_WB] columns in LDS
 __device__ __forceinline__ bool hit_mesh_exact(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
                                uint32_t *stack, float &t_out, uint32_t &tri_out) {
     const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));      // aabb.rs:33: 1.0 / r.direction()[a]
     const TriRay tr = make_triray(r);
     const float4 *nodes = sc.ref_blas + 2 * (size_t)ref_root;
-    int sp = 0;                                                          // stack: this lane's column of an LDS array [level][64]
+    int sp = 0;                                                          // stack: this thread's column of an LDS array [level][EXACT_WB]
     uint32_t cur = 0; bool have = false; float best = tmax; uint32_t best_tri = 0;
-    for (;;) {
-        const float4 lo = nodes[2 * (size_t)cur], hi = nodes[2 * (size_t)cur + 1];
-        const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w), kind = A >> 30;
-        if (hit_aabb(lo, hi, r.o, inv, tmin, tmax)) {
-            if (kind == 0u) { if (sp < EXACT_LEVELS) { stack[sp * 64] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }     // Branch: left = next node, right later
-            for (uint32_t k = 0; k < (kind == NODE_DOUBLE ? 2u : 1u); k++) {
-                const uint32_t item = k ? B : (A & NODE_MASK);
-                const float4 *tp = sc.tri + 3 * (size_t)(tri_base + item);
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                float t, b0, b1, b2;
-                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, tmin, tmax, t, b0, b1, b2))
-                    if (!have || !(best < t)) { have = true; best = t; best_tri = item; }
+    // while-while: every lane first goes down to its next leaf node (or runs out of tree); only then do the lanes test their
+    // triangles, together — with the leaf test inside the node loop every step of the wave paid for a triangle fetch from L2
+    // (one walk 150 us; this form ~60)
+    for (bool more = true; more;) {
+        uint32_t A = 0, B = 0; bool leaf = false;
+        for (;;) {
+            const float4 lo = nodes[2 * (size_t)cur], hi = nodes[2 * (size_t)cur + 1];
+            A = __float_as_uint(lo.w); B = __float_as_uint(hi.w);
+            if (hit_aabb(lo, hi, r.o, inv, tmin, tmax)) {
+                if ((A >> 30) == 0u) { if (sp < EXACT_LEVELS) { stack[sp * EXACT_WB] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }     // Branch: left = next node, right later
+                leaf = true; break;
             }
+            if (sp == 0) { more = false; break; }
+            sp--; cur = stack[sp * EXACT_WB];
         }
-        if (sp == 0) break;
-        sp--; cur = stack[sp * 64];
+        if (leaf) {
+            const bool two = (A >> 30) == NODE_DOUBLE;
+            const uint32_t i0 = A & NODE_MASK, i1 = two ? B : i0;
+            const float4 *p0 = sc.tri + 3 * (size_t)(tri_base + i0), *p1 = sc.tri + 3 * (size_t)(tri_base + i1);
+            const float4 a0 = p0[0], b0 = p0[1], c0 = p0[2], a1 = p1[0], b1 = p1[1], c1 = p1[2];     // both triangles of a DoubleLeaf requested at once
+            float t, u0, u1, u2;
+            if (hit_triangle(mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z), tr, tmin, tmax, t, u0, u1, u2))
+                if (!have || !(best < t)) { have = true; best = t; best_tri = i0; }
+            if (two && hit_triangle(mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z), tr, tmin, tmax, t, u0, u1, u2))
+                if (!have || !(best < t)) { have = true; best = t; best_tri = i1; }
+            if (sp == 0) more = false;
+            else { sp--; cur = stack[sp * EXACT_WB]; }
+        }
     }
     t_out = best; tri_out = best_tri;
     return have;
 }
 
 // shape dispatch in object space.  prim: rect3d face / mesh triangle, else 0.  EXACT: a mesh takes the literal reference walk
-// and aux0 is its reference tree's first node (k_extend_exact).
+// and aux0 is its reference tree's first node (k_exact_paths).
 template <bool EXACT = false>
 __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float4 q3, float4 q4, uint32_t aux0, uint32_t aux1,
                                           const Ray &r, float tmin, float tmax, uint32_t *stack_base, float &t, uint32_t &prim) {
@@ -1551,6 +1583,13 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
 // Stacks are 16-bit (LdsStack16).  Same arithmetic, same tie rules: the bits do not change.  The host launches it only
 // when nodes + stacks fit (launch_extend); bigger meshes keep k_blas.
 // Dynamic LDS: [pair nodes: 4 float4 each][16 stacks: levels x 64 x u16][queue counter].
+// Round 3, both built, measured on suzanne and removed (tools/experiments/*.diff, profiles/r03f_*, r03h_*):
+//  * rays handed out in windows of 512 sorted by direction octant x origin octant (counting sort in LDS): k_blas_lds 526 -> 534 us
+//    per launch, the frame 77.8 -> 80.6 ms — six bits of key do not make 64 incoherent bounce rays walk the same nodes;
+//  * TWO rays per lane (every lane holds two walks, a step issues both node reads before either's arithmetic; predicated, 111
+//    VGPRs): 74.5 -> 85.4 ms.  The walk does not wait for LDS LATENCY that a second instruction stream could hide: a predicated
+//    slot that does not walk still costs its 58 instructions, and the wave count per SIMD was never the limit either (r02: two
+//    workgroups per CU lost as well).  What the LDS walks are short of is coherence, and neither change buys any.
 // ------------------------------------------------------------------------------------------------
 constexpr int LDS_WAVES = 16;                      // waves per workgroup of the LDS-resident walks
 template <bool LDS_TRIS>
@@ -1763,12 +1802,10 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2-exact  k_extend_exact: the flagged rays of a segment (DExact, fw_device.h) traced once more by the literal algorithm of
-// the reference — scene.rs:137-149 (linear) or bvh.rs:115-151 over the reference's OWN trees (use_bvh) — after the fast
-// kernels; its hit records replace theirs.  One flag bit per slot, set by k_raygen / k_shade, consumed here.  The flagged
-// rays are a few per million (ill-conditioned triangle shears, noise hits from far away), so this kernel's speed does not
-// matter and it is written for clarity: nodes from L2, stacks in LDS.
-// With FIREWORK_EXACT_ALL=1 every ray takes it: the renderer then IS the reference's traversal (tests, tools/diverge.py).
+// K2-exact  closest_hit_exact: one ray by the literal algorithm of the reference — scene.rs:137-149 (linear) or bvh.rs:115-151
+// over the reference's OWN trees (use_bvh).  Used by k_exact_paths (behind k_shade below), which finishes the paths that have
+// left the wavefront (DExact, fw_device.h).  Written for clarity, not speed: nodes through generic pointers (LDS when the trees
+// fit, else L2), stacks in LDS.  With FIREWORK_EXACT_ALL=1 every path takes it: the renderer then IS the reference's traversal.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void closest_hit_exact(const DScene &sc, const Ray &r, const RngKey &key, int segment, bool use_bvh, uint32_t *tlas_stack,
                                                   uint32_t *blas_stack, float &best_t, uint32_t &best_obj, uint32_t &best_prim) {
@@ -1785,54 +1822,31 @@ __device__ __forceinline__ void closest_hit_exact(const DScene &sc, const Ray &r
     const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
     int sp = 0;
     uint32_t cur = 0; bool have = false;
-    for (;;) {
-        const float4 lo = sc.ref_tlas[2 * (size_t)cur], hi = sc.ref_tlas[2 * (size_t)cur + 1];
-        const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w), kind = A >> 30;
-        if (hit_aabb(lo, hi, r.o, inv, TMIN, TMAX)) {
-            if (kind == 0u) { if (sp < EXACT_LEVELS) { tlas_stack[sp * 64] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }
-            for (uint32_t k = 0; k < (kind == NODE_DOUBLE ? 2u : 1u); k++) {
+    for (bool more = true; more;) {          // while-while, like hit_mesh_exact: down to the next leaf node first, then the object tests together
+        uint32_t A = 0, B = 0; bool leaf = false;
+        for (;;) {
+            const float4 lo = sc.ref_tlas[2 * (size_t)cur], hi = sc.ref_tlas[2 * (size_t)cur + 1];
+            A = __float_as_uint(lo.w); B = __float_as_uint(hi.w);
+            if (hit_aabb(lo, hi, r.o, inv, TMIN, TMAX)) {
+                if ((A >> 30) == 0u) { if (sp < EXACT_LEVELS) { tlas_stack[sp * EXACT_WB] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }
+                leaf = true; break;
+            }
+            if (sp == 0) { more = false; break; }
+            sp--; cur = tlas_stack[sp * EXACT_WB];
+        }
+        if (leaf) {
+            for (uint32_t k = 0; k < ((A >> 30) == NODE_DOUBLE ? 2u : 1u); k++) {
                 const uint32_t item = k ? B : (A & NODE_MASK);
                 const Obj o = load_obj(sc.obj, item);
                 float t; uint32_t prim;
                 if (hit_object<true, true>(sc, o, item, r, TMIN, TMAX, blas_stack, key, segment, t, prim))
                     if (!have || !(best_t < t)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
             }
+            if (sp == 0) more = false;
+            else { sp--; cur = tlas_stack[sp * EXACT_WB]; }
         }
-        if (sp == 0) break;
-        sp--; cur = tlas_stack[sp * 64];
     }
 }
-// Two launches per segment: k_exact_scan reads the flag bitmap (one bit per slot, 1/256 of the queue bytes), clears it and
-// appends the flagged slots to one dense list; k_extend_exact walks the listed rays, one per lane, every lane busy.  (The first
-// version did both in one kernel, each wave for its own queue: a wave with ONE flagged ray then walked it with one lane
-// while the GPU waited — suzanne 72.7 -> 87.1 ms.)
-__global__ __launch_bounds__(BLOCK) void k_exact_scan(uint32_t *__restrict__ bits, uint32_t n_words, uint32_t *__restrict__ list, uint32_t *__restrict__ count) {
-    for (uint32_t wi = blockIdx.x * BLOCK + threadIdx.x; wi < n_words; wi += gridDim.x * BLOCK) {
-        uint32_t word = bits[wi];
-        if (!word) continue;
-        bits[wi] = 0u;                                               // consumed: the next segment's flags go into clean words
-        uint32_t at = atomicAdd(count, (uint32_t)__popc(word));
-        while (word) { const uint32_t b = (uint32_t)__ffs((int)word) - 1u; word &= word - 1u; list[at++] = wi * 32u + b; }
-    }
-}
-__global__ __launch_bounds__(WB) void k_extend_exact(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, int segment, int use_bvh,
-                                                     const uint32_t *__restrict__ list, const uint32_t *__restrict__ count) {
-    __shared__ uint32_t exact_stacks[2 * EXACT_LEVELS * 64];            // [TLAS | BLAS][level][lane] in LDS: a kernel that needs scratch memory
-                                                                          // (private stacks, calls) costs ~230 us per LAUNCH on this runtime —
-                                                                          // 110 launches were 25 of suzanne@64's 80 ms (profiles/r03f)
-    uint32_t *tlas_stack = exact_stacks + (threadIdx.x & 63u), *blas_stack = tlas_stack + EXACT_LEVELS * 64;
-    const uint32_t n = *count;
-    for (uint32_t k = blockIdx.x * WB + threadIdx.x; k < n; k += gridDim.x * WB) {
-        const uint32_t i = list[k];
-        const Ray r = make_ray(qld(&in.ray_a[i]), load_ray_b(in, i, f, segment), f, segment);
-        RngKey key{0, 0, 0};
-        if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
-        float best_t; uint32_t best_obj, best_prim;
-        closest_hit_exact(sc, r, key, segment, use_bvh != 0, tlas_stack, blas_stack, best_t, best_obj, best_prim);
-        hits[i] = pack_hit(best_t, best_obj, best_prim, sc.prim_bits);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // K5/K6  shading: textures, materials, environment
 // ------------------------------------------------------------------------------------------------
@@ -2223,8 +2237,9 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
             qst(&out.ray_a[dst], make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x));
             qst(&out.ray_b[dst], make_float2(nr.d.y, nr.d.z));
             qst(&out.state[dst], make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id)));
-            if (f.ex.mode && needs_exact(f.ex, nr.o.x, nr.o.y, nr.o.z, nr.d.x, nr.d.y, nr.d.z)) flag_exact(f.ex, dst);
         }
+        if (f.ex.mode)     // a new ray whose result depends on traversal order: its path leaves the wavefront here (DExact)
+            send_exact(f.ex, alive && needs_exact(f.ex, nr.o.x, nr.o.y, nr.o.z, nr.d.x, nr.d.y, nr.d.z), base + out_n + rank, nr.o, nr.d, nbeta, path_id, segment + 1);
         out_n += (uint32_t)__popcll(mask);
     };
     auto load_hit = [&](uint32_t idx) { return f.hit4 ? make_float2(0.f, __uint_as_float(reinterpret_cast<const uint32_t *>(hits)[idx])) : qld(&hits[idx]); };
@@ -2251,7 +2266,17 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
         if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); st_n = load_state(in, i + 64u, segment); hr_n = load_hit(i + 64u); }
         bool alive = false, later = false;
         Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
-        if (j < n) {
+        bool gone = false;                                   // this slot's path has left the wavefront (k_exact_paths finishes it)
+        if (f.ex.mode) {
+            const uint32_t wd = (j < n) ? f.ex.bits[i >> 5] : 0u;
+            gone = ((wd >> (i & 31u)) & 1u) != 0u;
+            const unsigned long long gm = __ballot(gone);      // consumed: cleared with an atomic AND, so that a flag this wave's own
+            if (gm && lane < 2u) {                              // compaction sets in the same word afterwards can never be lost
+                const uint32_t m = lane ? (uint32_t)(gm >> 32) : (uint32_t)gm;
+                if (m) atomicAnd(&f.ex.bits[((base + c0) >> 5) + lane], ~m);
+            }
+        }
+        if (j < n && !gone) {
             Ray r = make_ray(ra, rb, f, segment);
             V3 beta = mk(st.x, st.y, st.z);
             path_id = __float_as_uint(st.w);
@@ -2272,6 +2297,66 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     }
     if (MODE == 2) while (list_n) run_list(min(list_n, 64u));
     if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-exact  k_exact_paths: the paths that left the wavefront (DExact), finished here — one launch per batch, after its last k_shade.
+//
+// Each lane takes one listed path and follows it to its end: closest_hit_exact for every remaining segment (the literal walk is
+// the reference's semantics for ANY ray, so a path that needed it once keeps it), k_shade's own shade_path for the hit, the
+// radiance deposited at the path's home slot like every other path's.  Its rays beyond the one it was flagged with are added to
+// the batch's per-depth ray counts.
+// (The first two versions traced the flagged rays of every SEGMENT in their own launch and handed the hits back to k_shade:
+// one walk without culling takes ~150 us — a wave's lanes alternate between node steps and triangle tests — and a launch lasts
+// as long as its longest walk, 22 launches per batch: suzanne @64 spp 9.7 -> 14.7 ms for 0.07 % of its rays, whether the trees sat
+// in L2 or in LDS.  Here that latency is paid once per batch and overlaps the other batch's kernels.)
+// Dynamic LDS: [ref TLAS nodes][ref BLAS nodes] (lds_trees) [TLAS stacks: tlas_levels x 256 u32][BLAS stacks: blas_levels x 256 u32].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EXACT_WB) void k_exact_paths(DScene sc, DFrame f, float4 *__restrict__ sample_rad, uint32_t *__restrict__ totals, int use_bvh,
+                                                          uint32_t lds_trees, uint32_t n_tlas_q, uint32_t n_blas_q, uint32_t tlas_levels, uint32_t blas_levels,
+                                                          uint32_t fast_tlas_levels, uint32_t fast_levels) {
+    extern __shared__ float4 lds_exact[];
+    const uint32_t n = min(*f.ex.list_count, f.ex.list_cap);
+    if (n == 0u) return;
+    if (sc.has_perlin) stage_perm();
+    DScene scl = sc;
+    float4 *p = lds_exact;
+    if (lds_trees) {
+        for (uint32_t k = threadIdx.x; k < n_tlas_q; k += EXACT_WB) p[k] = sc.ref_tlas[k];
+        for (uint32_t k = threadIdx.x; k < n_blas_q; k += EXACT_WB) p[n_tlas_q + k] = sc.ref_blas[k];
+        scl.ref_tlas = p; scl.ref_blas = p + n_tlas_q;
+        p += n_tlas_q + n_blas_q;
+    }
+    __syncthreads();
+    uint32_t *tlas_stack = reinterpret_cast<uint32_t *>(p) + threadIdx.x, *blas_stack = tlas_stack + (size_t)tlas_levels * EXACT_WB;
+    // the stacks of the ordinary (culled) walk, [level][lane] per wave like everywhere else: the segments of a listed path that
+    // are NOT flagged themselves take closest_hit — by the flag rule their result does not depend on the walk — so that a
+    // path costs one or two literal walks (~150 us each) and not eleven
+    uint32_t *fast_stack = reinterpret_cast<uint32_t *>(p) + (size_t)(tlas_levels + blas_levels) * EXACT_WB + (size_t)(threadIdx.x >> 6) * fast_levels * 64u + (threadIdx.x & 63u);
+    uint32_t *fast_blas_stack = fast_stack + (size_t)fast_tlas_levels * 64u;
+    for (uint32_t k = blockIdx.x * EXACT_WB + threadIdx.x; k < n; k += gridDim.x * EXACT_WB) {
+        const float4 e0 = f.ex.list[3 * (size_t)k], e1 = f.ex.list[3 * (size_t)k + 1], e2 = f.ex.list[3 * (size_t)k + 2];
+        Ray r{mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y)};
+        V3 beta = mk(e1.z, e1.w, e2.x);
+        const uint32_t home = __float_as_uint(e2.y);
+        int seg = (int)__float_as_uint(e2.z);
+        const RngKey key = key_of(f, home);
+        for (bool first = true;; first = false) {
+            if (!first) atomicAdd(&totals[seg], 1u);                   // the flagged segment itself sits in the wavefront's queue counts
+            float t = 2e9f; uint32_t obj = MISS, prim = 0;
+            if (first || needs_exact(f.ex, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z))
+                closest_hit_exact(scl, r, key, seg, use_bvh != 0, tlas_stack, blas_stack, t, obj, prim);
+            else {
+                bool deferred = false; uint32_t dobj = 0;
+                if (use_bvh) closest_hit<true, false>(sc, r, key, seg, fast_stack, fast_blas_stack, t, obj, prim, deferred, dobj);
+                else closest_hit<false, false>(sc, r, key, seg, fast_stack, fast_blas_stack, t, obj, prim, deferred, dobj);
+            }
+            const uint32_t code = obj == MISS ? MISS : ((obj << sc.prim_bits) | prim);
+            Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0);
+            if (!shade_path<false>(sc, f, sc.obj, sc.mat, sc.tex, r, beta, home, t, code, seg, sample_rad, nr, nbeta)) break;
+            r = nr; beta = nbeta; seg++;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2570,7 +2655,7 @@ void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPat
 // More than 64 KB of dynamic LDS has to be allowed per kernel AND per device (a process may drive several: fw_render_scene_tiled):
 // true the first time kernel group `which` is about to be launched on the current device.
 static bool lds_attr_needed(int which) {
-    static std::atomic<unsigned char> done[2][64];
+    static std::atomic<unsigned char> done[3][64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
     return done[which][dev].exchange(1) == 0;
@@ -2616,11 +2701,18 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)(DEFER0_CAP + DEFER1_CAP) * 12, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
-void launch_extend_exact(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float2 *hits, int segment, bool use_bvh,
-                         uint32_t *list, uint32_t *count) {
-    const uint32_t n_words = (c.q.n_waves * c.q.cap + 31u) / 32u;
-    hipLaunchKernelGGL(k_exact_scan, dim3(std::min<uint32_t>((n_words + BLOCK - 1) / BLOCK, (uint32_t)c.n_cus * 8u)), dim3(BLOCK), 0, c.stream, f.ex.bits, n_words, list, count);
-    hipLaunchKernelGGL(k_extend_exact, dim3((uint32_t)c.n_cus * 8u), dim3(WB), 0, c.stream, sc, f, in, hits, segment, use_bvh ? 1 : 0, list, count);
+void launch_exact_paths(const LaunchCfg &c, const DScene &sc, const DFrame &f, float4 *sample_rad, uint32_t *totals, bool use_bvh) {
+    // stacks sized by the reference trees' depths; the trees themselves in LDS when they fit beside the stacks
+    const uint32_t tl = std::min<uint32_t>(c.ref_tlas_depth + 2u, EXACT_LEVELS), bl = std::min<uint32_t>(c.ref_blas_depth + 2u, EXACT_LEVELS);
+    const uint32_t ftl = use_bvh ? (uint32_t)c.tlas_depth + 1u : 0u, fl = ftl + (uint32_t)c.blas_depth + 1u;     // the ordinary walk's levels (launch_extend)
+    const size_t stacks = (size_t)(tl + bl) * EXACT_WB * 4 + (size_t)(EXACT_WB / 64) * fl * 64 * 4, trees = ((size_t)c.ref_tlas_nodes + c.ref_blas_nodes) * 32;
+    const bool lds_trees = stacks + trees <= 96 * 1024;
+    const size_t lds = stacks + (lds_trees ? trees : 0);
+    if (lds > 48 * 1024 && lds_attr_needed(2)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_paths), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024));
+    // workgroups per CU: 3 x 256 threads are the 3 waves per SIMD its 136 VGPRs allow; fewer when the LDS copy of the trees is big
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (150 * 1024) / std::max<size_t>(lds, 1)));
+    hipLaunchKernelGGL(k_exact_paths, dim3((uint32_t)c.n_cus * per_cu), dim3(EXACT_WB), lds, c.stream, sc, f, sample_rad, totals, use_bvh ? 1 : 0,
+                       lds_trees ? 1u : 0u, c.ref_tlas_nodes * 2u, c.ref_blas_nodes * 2u, tl, bl, ftl, fl);
 }
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment) {

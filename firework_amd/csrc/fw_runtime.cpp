@@ -571,7 +571,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     try { bvh_build(tlas, world); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
     std::vector<uint32_t> obj_rank = reference_ranks(tlas, desc->n_objects);
     uint32_t ref_tlas_nodes = tlas.count();
-    const std::vector<float> ref_tlas = tlas.nodes;          // the reference's own tree: what k_extend_exact walks
+    const std::vector<float> ref_tlas = tlas.nodes;          // the reference's own tree: what k_exact_paths walks
     const uint32_t ref_tlas_depth = tlas.depth;
     {   // the exact walk's flag rule (fw_device.h DExact)
         if (!fl.tri.empty()) ex.mode |= 1u;
@@ -584,7 +584,8 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
             const V3 c = box_center(cl), h = cl.mx - c;
             const float radius = std::fmax(h.x, std::fmax(h.y, h.z));
             ex.far_c[0] = c.x; ex.far_c[1] = c.y; ex.far_c[2] = c.z;
-            ex.far_r = std::fmax(128.f * min_size, 2.f * radius);   // noise / signal of a sphere's discriminant = 2^-23 (|o| / r)^2 <~ 1e-2 inside
+            ex.far_r = std::fmax(1024.f * min_size, 2.f * radius);  // noise / signal of a sphere's discriminant = 2^-23 (|o| / r)^2 = 2^-23 (2 |o| / size)^2: 1/2 at this distance
+                                                                    // (128 x flagged every camera ray of teapot.rs, whose camera sits 16 units from triangles of 0.08)
             const float pad = 2.f * min_size + 1e-3f * radius;
             ex.box_lo[0] = cl.mn.x - pad; ex.box_lo[1] = cl.mn.y - pad; ex.box_lo[2] = cl.mn.z - pad;
             ex.box_hi[0] = cl.mx.x + pad; ex.box_hi[1] = cl.mx.y + pad; ex.box_hi[2] = cl.mx.z + pad;
@@ -928,8 +929,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         need(L.sample_rad, (size_t)cap * 16);                 // indexed by home slot
         need(L.dep_bits, ((size_t)cap + 31) / 32 * 4);        // one bit per slot: "a radiance record was written here" (black environments)
         if (exact_mode) {
-            need(L.exact_bits, ((size_t)cap + 63) / 64 * 8 + 64);        // one bit per slot: "trace this ray by the reference walk as well", + 11 per-segment list counters
-            need(L.exact_list, (size_t)cap * 4);                         // the flagged slots of one segment, dense (k_exact_scan -> k_extend_exact)
+            need(L.exact_bits, ((size_t)cap + 63) / 64 * 8 + 64);        // one bit per slot: "this path has left the wavefront", + the list's counter
+            need(L.exact_list, (size_t)max_paths * 48);                  // the paths that left (ray + throughput + home slot + segment): at most every path of the batch
         }
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
         if (park_meshes) {     // rays handed from k_extend_tlas_park to k_blas: 40 B per slot
@@ -980,8 +981,12 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.no_lds_tris = getenv("FIREWORK_NO_LDS_TRIS") != nullptr;
     cfg.n_defer = (!p->use_bvh && getenv("FIREWORK_NO_DEFER") == nullptr) ? sc->n_defer : 0u;
     cfg.lds_trees = getenv("FIREWORK_NO_LDS_TREES") == nullptr;
+    cfg.ref_tlas_nodes = sc->tlas_nodes; cfg.ref_blas_nodes = sc->blas_nodes; cfg.ref_tlas_depth = sc->ref_tlas_depth; cfg.ref_blas_depth = sc->ref_blas_depth;
     // k_shade's list entries are 16-bit queue positions: longer queues (cap > 65536: never with the default geometry) shade in line
-    cfg.shade_mode = (getenv("FIREWORK_NO_SHADE_DEFER") != nullptr || q.cap > 65536u) ? 0 : (sc->has_expensive ? 2 : 1);
+    // Default: the cheap loop alone where the scene has nothing expensive (cornell k_shade -5 %), everything in line otherwise — the
+    // list (mode 2) is slower wherever it was measured (gpurun_out/r03h: part2@16 11.7 -> 12.0 ms, hdri@64 5.5 -> 6.1, random_spheres
+    // 1.90 -> 1.98, volume@64 6.08 -> 6.12) and stays behind FIREWORK_SHADE_LIST=1; FIREWORK_NO_SHADE_DEFER=1 forces mode 0.
+    cfg.shade_mode = getenv("FIREWORK_NO_SHADE_DEFER") != nullptr ? 0 : (!sc->has_expensive ? 1 : ((getenv("FIREWORK_SHADE_LIST") != nullptr && q.cap <= 65536u) ? 2 : 0));
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
@@ -1005,7 +1010,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // launch k is the start of launch k+1 of that lane.  With several lanes the intervals overlap in wall time.
     const bool timing = (p->flags & FW_FLAG_TIME_KERNELS) != 0;
     const bool count_deposits = (p->flags & FW_FLAG_COUNT_DEPOSITS) != 0 && fr.skip_zero_deposits != 0;   // otherwise every terminated path writes one
-    const size_t per_batch_launches = 1 + 2 * fw::MAX_SEGMENTS + 2;
+    const size_t per_batch_launches = 1 + 2 * fw::MAX_SEGMENTS + 3;     // raygen, 11 x (extend, shade), exact paths, queue totals, accumulate
     std::vector<std::vector<int>> ev_class(n_lanes);   // per lane: class of the launch that ENDS at events[1 + k]
     std::vector<size_t> ev_next(n_lanes, 0);
     if (timing) for (int l = 0; l < n_lanes; l++) {
@@ -1045,10 +1050,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         fr.sample0 = first_sample + b * spp_b;
         fr.dep_bits = (uint32_t *)L.dep_bits.p;
         if (fr.skip_zero_deposits) HIPCHK(hipMemsetAsync(fr.dep_bits, 0, ((size_t)cap + 31) / 32 * 4, ls));
-        uint32_t *ex_counts = nullptr;
         if (exact_mode) {
             fr.ex.bits = (uint32_t *)L.exact_bits.p;
-            ex_counts = fr.ex.bits + ((size_t)cap + 63) / 64 * 2;       // behind the bitmap
+            fr.ex.list_count = fr.ex.bits + ((size_t)cap + 63) / 64 * 2;       // behind the bitmap
+            fr.ex.list = (float4 *)L.exact_list.p; fr.ex.list_cap = max_paths;
             HIPCHK(hipMemsetAsync(fr.ex.bits, 0, ((size_t)cap + 63) / 64 * 8 + 64, ls));
         }
         fr.spp_batch = std::min(spp_b, p->samples - b * spp_b);
@@ -1066,8 +1071,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
             if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
             else {
-                timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park);
-                               if (exact_mode) fw::launch_extend_exact(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, (uint32_t *)L.exact_list.p, ex_counts + seg); });
+                timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park); });
                 if (dump_one) {     // debug (tools/diverge.py): the one path of this call sits in slot 0 of wave 0 in every segment
                     float *r = &dump_rec[(size_t)seg * 16];
                     uint32_t alive = 0;
@@ -1083,7 +1087,15 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             }
             cur ^= 1;
         }
+        // the paths that left the wavefront (DExact) are finished here, once per batch, with the reference's own walk
+        if (exact_mode) timed(1, [&] { fw::launch_exact_paths(cfg, sc->d, fr, srad, totals, use_bvh); });
         timed(3, [&] { fw::launch_queue_totals(cfg, totals, park.ptotal); });
+        if (exact_mode && getenv("FIREWORK_TRACE")) {          // how many paths took the exact walk (debug: synchronises)
+            uint32_t c = 0;
+            HIPCHK(hipMemcpyAsync(&c, fr.ex.list_count, 4, hipMemcpyDeviceToHost, ls));
+            HIPCHK(hipStreamSynchronize(ls));
+            fprintf(stderr, "[firework] batch %u: %u of %u paths left the wavefront for the exact walk\n", b, c, n_paths);
+        }
         if (count_deposits) fw::launch_count_deposits(cfg, fr.dep_bits, totals + 12);   // not a kernel class: after the last timed event of its neighbours
         // `total_color += color(..)` in sample order (render.rs:181): batch b is accumulated after batch b-1, whichever
         // lanes they ran on, so the image does not depend on the number of lanes or batches

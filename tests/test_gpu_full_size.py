@@ -23,7 +23,7 @@ def full_check(oracle, scene, renderer, name):
     """GPU vs oracle, same seed: every path takes the same segments (ray counts per depth equal), every u8 of the image is
     equal, and the float means agree to the rounding of a different product order (beta is multiplied left to right on the
     device, right to left by the reference's recursion).  No pixel is tolerated: the libm-class functions are glibc's
-    (fw_libm.h) and the rays whose result depends on traversal order take the reference's own walk (k_extend_exact)."""
+    (fw_libm.h) and the rays whose result depends on traversal order take the reference's own walk (k_exact_paths)."""
     gpu = renderer.render_full(scene)
     cpu = oracle.render(scene, renderer)
     g, c = np.nan_to_num(gpu.gamma.astype(np.float64)), np.nan_to_num(cpu.gamma.astype(np.float64))
@@ -185,6 +185,12 @@ def test_bench_line_carries_roofline_parity_and_one_shot():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     lay, sur = d["roofline_frame"]["layout"], d["roofline_frame"]["survey"]
     assert 0 < lay["bytes"] < sur["bytes"]
+    # round 3: the timed loop runs the library's own schedule, per-kernel times come from a labelled exclusive pass
+    sch = d["schedule"]
+    assert sch["timed_loop_ms_per_step"] == d["ms_per_step"] and sch["exclusive_pass_ms_per_step"] > 0 and "FIREWORK_STREAMS=1" in sch["exclusive_pass"]
+    assert d["device"]["copy_GBps"] > 100 and d["device"]["cus"] >= 1
+    cold = d["one_shot_cold"]
+    assert cold["ms_wall"] > o["ms_wall"] and cold["ms_scene"] >= 0 and cold["ms_render"] > 0       # a process's first call pays for pools and code objects
 
 
 def test_stats_carry_the_layouts_own_bytes_and_the_deposits_really_written():
@@ -202,7 +208,8 @@ def test_stats_carry_the_layouts_own_bytes_and_the_deposits_really_written():
     assert a["bytes_extend"] == rd_ray + 4 * a["rays"]                # 4-byte hit records: spheres, rects and boxes only (hit4)
     assert a["bytes_shade"] == rd_ray + later * 16 + 4 * a["rays"] + later * 40 + a["deposits"] * 16
     assert a["bytes_raygen"] == S * ray0 + S * 4                      # rays + the tile-order ids (no zero records: dep_bits)
-    assert a["bytes_accumulate"] == a["deposits"] * 16 + S // 8 + 96 * 96 * 2 * 16   # records with a set bit, the bits, the accumulator
+    assert a["n_batches"] == 2                                        # a box-list scene: two batches in flight (round 3)
+    assert a["bytes_accumulate"] == a["deposits"] * 16 + S // 8 + a["n_batches"] * 96 * 96 * 2 * 16   # records with a set bit, the bits, the accumulator per batch
     b = r.render_full(s).stats                                        # again, same workspace: same count
     assert b["deposits"] == a["deposits"]
     c = r.count_deposits(False).render_full(s).stats

@@ -5,6 +5,9 @@
 TAG=$1; shift
 export TMPDIR=/tmp; R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O && cd /tmp
 B="--no-cpu-baseline --no-one-shot"
+# one batch in flight in every frame of these passes (round 3: the library's own schedule overlaps two batches, whose launches
+# carry half a frame each): per-launch averages then mean the same thing as bench.py's exclusive pass, which the roofline quotes
+export FIREWORK_STREAMS=1
 (cd $R && python3 -c "import bench; print(bench.kernel_source_sha())") > $O/source_sha.txt     # the build these passes ran
 pass() { local name=$1; shift; local ctr="$1"; shift
   if [ -n "$ctr" ]; then timeout -k 10 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$name -- python3 $R/bench.py "$@" --steps 1 --warmup 0 $B > $O/$name.log 2>&1

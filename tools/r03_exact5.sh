@@ -1,0 +1,12 @@
+#!/bin/bash
+set -o pipefail
+OUT=$PWD/gpurun_out/$1; mkdir -p $OUT; R=$PWD
+timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tee $OUT/pytest.log | tail -4
+run() { timeout -k 10 300 python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-shot $2 2>$OUT/err.txt | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('kernel_ms_per_step',{}); print('$1', 'ms', round(d['ms_per_step'],2), 'excl', round(d['schedule']['exclusive_pass_ms_per_step'],2), 'ext', round(k.get('ms_extend',0),2), 'shd', round(k.get('ms_shade',0),2))" || tail -5 $OUT/err.txt; }
+echo "== exact walk on / off"
+for cfg in "--config C3_suzanne --spp 64" "--config C3_suzanne" "--config C5_part2_all --spp 16" "--config teapot --spp 32"; do
+  for i in 1 2; do run "exact   $cfg" "$cfg"; FIREWORK_NO_EXACT=1 run "noexact $cfg" "$cfg"; done
+done 2>&1 | tee $OUT/exact_ab.txt
+echo "== two lanes for hdri / volume?"
+runq() { timeout -k 10 300 python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-shot --no-kernel-timing $2 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', 'ms', round(d['ms_per_step'],2))"; }
+for cfg in "--config C4a_hdri_test" "--config C4b_volume_test"; do for i in 1 2; do for n in 1 2; do FIREWORK_STREAMS=$n runq "streams=$n $cfg" "$cfg"; done; done; done 2>&1 | tee $OUT/lanes_sky.txt
