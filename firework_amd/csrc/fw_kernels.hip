@@ -732,42 +732,106 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
 // both children always, nothing culled; the smaller t wins, a tie goes to the later item (`if lh.t < rh.t {lh} else {rh}`).
 // ref_root = first node of the mesh's tree in sc.ref_blas (child indices are relative to it).
 constexpr int EXACT_LEVELS = 40;    // a median-split tree over N items is ceil(log2 N) deep: < 2^32 items
-constexpr int EXACT_WB = 256;       // threads per workgroup of k_exact_paths: its stacks are [level][EXACT_WB] columns in LDS
+constexpr int EXACT_STACK = 512;    // entries of the stack the 64 lanes of a wave share in hit_mesh_exact
+constexpr int EXACT_WB = 64;        // threads per workgroup of k_exact_paths: its stacks are [level][EXACT_WB] columns in LDS.  Single waves with a few KB of LDS:
+                                    // they have to fit on a CU next to the LDS-resident walks' 137-150 KB (with 256 threads and the reference trees in LDS they did not,
+                                    // and the other batch's k_blas_lds waited for them: suzanne 80 -> 99 ms)
+// The reference's walk over one mesh, node by node in its own order (bvh.rs:92-131): every lane of the wave the same walk (see
+// hit_mesh_exact, which calls this when the order of the tests matters).  ws: the wave's shared stack.
+__device__ __forceinline__ bool hit_mesh_exact_serial(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
+                                                   uint32_t *ws, float &t_out, uint32_t &tri_out) {
+    const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+    const TriRay tr = make_triray(r);
+    const float4 *nodes = sc.ref_blas + 2 * (size_t)ref_root;
+    int sp = 0;
+    uint32_t cur = 0; bool have = false; float best = tmax; uint32_t best_tri = 0;
+    for (;;) {
+        const float4 lo = nodes[2 * (size_t)cur], hi = nodes[2 * (size_t)cur + 1];
+        const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
+        if (hit_aabb(lo, hi, r.o, inv, tmin, tmax)) {
+            if ((A >> 30) == 0u) { if (sp < EXACT_LEVELS) { ws[sp] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }     // Branch: left = next node, right later
+            const bool two = (A >> 30) == NODE_DOUBLE;
+            for (uint32_t k = 0; k < (two ? 2u : 1u); k++) {
+                const uint32_t i = k ? B : (A & NODE_MASK);
+                const float4 *pt = sc.tri + 3 * (size_t)(tri_base + i);
+                const float4 a = pt[0], b = pt[1], c = pt[2];
+                float t, u0, u1, u2;
+                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, tmin, tmax, t, u0, u1, u2))
+                    if (!have || !(best < t)) { have = true; best = t; best_tri = i; }
+            }
+        }
+        if (sp == 0) break;
+        sp--; cur = ws[sp];
+    }
+    t_out = best; tri_out = best_tri;
+    return have;
+}
+
 __device__ __forceinline__ bool hit_mesh_exact(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
                                uint32_t *stack, float &t_out, uint32_t &tri_out) {
+    // ONE RAY PER WAVE: the 64 lanes hold the same ray (k_exact_paths runs one path per wave, every lane the same instructions
+    // on the same values) and share this walk.  The reference's walk (bvh.rs:92-131) never narrows its interval: it tests every
+    // node whose ancestors' boxes the ray hits with the caller's (tmin, tmax), and of the triangles hit it returns the smallest
+    // t, the LATER one in its depth-first order on a tie (`!(best < t)` replaces).  Neither the set of nodes nor that choice
+    // depends on the order of the tests, so the lanes pop up to 64 nodes of a shared stack per round, and the wave reduces
+    // (t, depth-first position) at the end; the nodes lie in depth-first order (left child = next node), so the position is the
+    // node's index.  A walk is then ~depth rounds of one L2 latency each instead of one latency per node visited (60-150 us),
+    // and the lanes of a wave no longer wait for each other's different paths.
+    // One case does depend on the order: mesh.rs:164-177 lets a NaN t through (no comparison rejects it), and `!(best < t)` then
+    // replaces whatever came before and is replaced by whatever comes next.  A wave that meets one walks again, in order.
+    const uint32_t lane = threadIdx.x & 63u;
     const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));      // aabb.rs:33: 1.0 / r.direction()[a]
     const TriRay tr = make_triray(r);
     const float4 *nodes = sc.ref_blas + 2 * (size_t)ref_root;
-    int sp = 0;                                                          // stack: this thread's column of an LDS array [level][EXACT_WB]
-    uint32_t cur = 0; bool have = false; float best = tmax; uint32_t best_tri = 0;
-    // while-while: every lane first goes down to its next leaf node (or runs out of tree); only then do the lanes test their
-    // triangles, together — with the leaf test inside the node loop every step of the wave paid for a triangle fetch from L2
-    // (one walk 150 us; this form ~60)
-    for (bool more = true; more;) {
-        uint32_t A = 0, B = 0; bool leaf = false;
-        for (;;) {
-            const float4 lo = nodes[2 * (size_t)cur], hi = nodes[2 * (size_t)cur + 1];
-            A = __float_as_uint(lo.w); B = __float_as_uint(hi.w);
-            if (hit_aabb(lo, hi, r.o, inv, tmin, tmax)) {
-                if ((A >> 30) == 0u) { if (sp < EXACT_LEVELS) { stack[sp * EXACT_WB] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }     // Branch: left = next node, right later
-                leaf = true; break;
-            }
-            if (sp == 0) { more = false; break; }
-            sp--; cur = stack[sp * EXACT_WB];
+    uint32_t *ws = stack - lane;                                         // the wave's EXACT_STACK entries
+    bool have = false, nan_t = false; float best = tmax; uint32_t best_tri = 0, best_pos = 0;
+    uint32_t sp = 1;                                                     // wave-uniform
+    if (lane == 0) ws[0] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    while (sp > 0u) {
+        // as many nodes as fit: a round pops k and pushes at most 2k; with little room left the wave goes node by node, which
+        // needs at most one more entry per level of the tree below the node (EXACT_LEVELS, kept free)
+        const int room = EXACT_STACK - EXACT_LEVELS - 8 - (int)sp;
+        uint32_t k = min(64u, sp);
+        if ((int)k > room) k = (uint32_t)max(1, room);
+        const bool active = lane < k;
+        const uint32_t node = active ? ws[sp - 1u - lane] : 0u;
+        sp -= k;
+        float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+        if (active) { lo = nodes[2 * (size_t)node]; hi = nodes[2 * (size_t)node + 1]; }
+        const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
+        const bool hitb = active && hit_aabb(lo, hi, r.o, inv, tmin, tmax);
+        const bool branch = hitb && (A >> 30) == 0u;
+        const unsigned long long m = __ballot(branch);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");           // the pops above before the pushes below
+        if (branch) {
+            const uint32_t at = sp + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            ws[at] = A & NODE_MASK; ws[at + 1u] = node + 1u;
         }
-        if (leaf) {
+        sp += 2u * (uint32_t)__popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (hitb && !branch) {
             const bool two = (A >> 30) == NODE_DOUBLE;
             const uint32_t i0 = A & NODE_MASK, i1 = two ? B : i0;
             const float4 *p0 = sc.tri + 3 * (size_t)(tri_base + i0), *p1 = sc.tri + 3 * (size_t)(tri_base + i1);
             const float4 a0 = p0[0], b0 = p0[1], c0 = p0[2], a1 = p1[0], b1 = p1[1], c1 = p1[2];     // both triangles of a DoubleLeaf requested at once
             float t, u0, u1, u2;
-            if (hit_triangle(mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z), tr, tmin, tmax, t, u0, u1, u2))
-                if (!have || !(best < t)) { have = true; best = t; best_tri = i0; }
-            if (two && hit_triangle(mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z), tr, tmin, tmax, t, u0, u1, u2))
-                if (!have || !(best < t)) { have = true; best = t; best_tri = i1; }
-            if (sp == 0) more = false;
-            else { sp--; cur = stack[sp * EXACT_WB]; }
+            if (hit_triangle(mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z), tr, tmin, tmax, t, u0, u1, u2)) {
+                nan_t |= t != t;
+                if (!have || t < best || (t == best && 2u * node > best_pos)) { have = true; best = t; best_tri = i0; best_pos = 2u * node; }
+            }
+            if (two && hit_triangle(mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z), tr, tmin, tmax, t, u0, u1, u2)) {
+                nan_t |= t != t;
+                if (!have || t < best || (t == best && 2u * node + 1u > best_pos)) { have = true; best = t; best_tri = i1; best_pos = 2u * node + 1u; }
+            }
         }
+    }
+    if (__ballot(nan_t) != 0ull) return hit_mesh_exact_serial(sc, ref_root, tri_base, r, tmin, tmax, ws, t_out, tri_out);
+    for (int d = 1; d < 64; d <<= 1) {            // butterfly: every lane ends with the wave's winner
+        const bool oh = __shfl_xor((int)have, d) != 0;
+        const float ot = __shfl_xor(best, d);
+        const uint32_t otri = (uint32_t)__shfl_xor((int)best_tri, d), opos = (uint32_t)__shfl_xor((int)best_pos, d);
+        if (oh && (!have || ot < best || (ot == best && opos > best_pos))) { have = true; best = ot; best_tri = otri; best_pos = opos; }
     }
     t_out = best; tri_out = best_tri;
     return have;
@@ -2228,7 +2292,7 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     const uint32_t base = w * q.cap;
     uint32_t out_n = 0;                                                  // survivors written so far (wave-uniform)
     uint32_t list_n = 0;                                                 // MODE 2: entries of shade_list (wave-uniform)
-    // ---- K7: compaction inside the wave's private queue: ballot -> mbcnt prefix -> dense stores --------
+// ---- K7: compaction inside the wave's private queue: ballot -> mbcnt prefix -> dense stores --------
     auto compact = [&](bool alive, const Ray &nr, V3 nbeta, uint32_t path_id) {
         const unsigned long long mask = __ballot(alive);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -2299,6 +2363,17 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
 }
 
+#ifdef FW_EXACT_PROF
+// debug builds (-DFW_EXACT_PROF, tools/exact_prof.py): where k_exact_paths' time goes.  [0] paths [1] segments [2] literal walks
+// [3] clocks in literal walks [4] ordinary walks [5] clocks in them [6] clocks shading [7] clocks of all paths [8] longest path
+// [9] its segments [10] kernel launches (s_memrealtime: 100 MHz)
+__device__ unsigned long long g_xprof[16];
+#define XP_ADD(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_xprof[k], (unsigned long long)(v)); } while (0)
+#define XP_NOW() wall_clock64()
+#else
+#define XP_ADD(k, v) do { } while (0)
+#define XP_NOW() 0ull
+#endif
 // ------------------------------------------------------------------------------------------------
 // K-exact  k_exact_paths: the paths that left the wavefront (DExact), finished here — one launch per batch, after its last k_shade.
 //
@@ -2310,53 +2385,69 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
 // one walk without culling takes ~150 us — a wave's lanes alternate between node steps and triangle tests — and a launch lasts
 // as long as its longest walk, 22 launches per batch: suzanne @64 spp 9.7 -> 14.7 ms for 0.07 % of its rays, whether the trees sat
 // in L2 or in LDS.  Here that latency is paid once per batch and overlaps the other batch's kernels.)
-// Dynamic LDS: [ref TLAS nodes][ref BLAS nodes] (lds_trees) [TLAS stacks: tlas_levels x 256 u32][BLAS stacks: blas_levels x 256 u32].
+// Dynamic LDS: [TLAS stacks: tlas_levels x 64 u32][BLAS stacks: blas_levels x 64 u32][the ordinary walk's stacks: fast_levels x 64 u32].
+// (The reference trees in LDS instead of L2 changed nothing that could be measured: a literal walk is long because it is literal.)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(EXACT_WB) void k_exact_paths(DScene sc, DFrame f, float4 *__restrict__ sample_rad, uint32_t *__restrict__ totals, int use_bvh,
-                                                          uint32_t lds_trees, uint32_t n_tlas_q, uint32_t n_blas_q, uint32_t tlas_levels, uint32_t blas_levels,
-                                                          uint32_t fast_tlas_levels, uint32_t fast_levels) {
+                                                          uint32_t tlas_levels, uint32_t blas_levels, uint32_t fast_tlas_levels, uint32_t fast_levels) {
     extern __shared__ float4 lds_exact[];
+    __shared__ uint32_t seg_rays[MAX_SEGMENTS];       // this workgroup's rays per depth: one global atomic per workgroup and depth at the end
+                                                      // (one per RAY on eleven addresses was 2.3 of the kernel's 5 ms: ~88 atomics per us per address)
     const uint32_t n = min(*f.ex.list_count, f.ex.list_cap);
     if (n == 0u) return;
+    if (threadIdx.x < (uint32_t)MAX_SEGMENTS) seg_rays[threadIdx.x] = 0u;
     if (sc.has_perlin) stage_perm();
-    DScene scl = sc;
+    const DScene &scl = sc;
     float4 *p = lds_exact;
-    if (lds_trees) {
-        for (uint32_t k = threadIdx.x; k < n_tlas_q; k += EXACT_WB) p[k] = sc.ref_tlas[k];
-        for (uint32_t k = threadIdx.x; k < n_blas_q; k += EXACT_WB) p[n_tlas_q + k] = sc.ref_blas[k];
-        scl.ref_tlas = p; scl.ref_blas = p + n_tlas_q;
-        p += n_tlas_q + n_blas_q;
-    }
     __syncthreads();
-    uint32_t *tlas_stack = reinterpret_cast<uint32_t *>(p) + threadIdx.x, *blas_stack = tlas_stack + (size_t)tlas_levels * EXACT_WB;
-    // the stacks of the ordinary (culled) walk, [level][lane] per wave like everywhere else: the segments of a listed path that
+    // ONE PATH PER WAVE (a workgroup is one wave): all 64 lanes carry the same path and execute the same instructions on the same
+    // values — the scalar part of a path costs what it cost one lane, no lane waits for another lane's different path (with 64
+    // paths per wave the wave's time was the SUM of its lanes' walks), a batch's few thousand paths fill the GPU's wave slots
+    // instead of a few dozen, and the literal mesh walk is shared by the lanes (hit_mesh_exact).  Stores of the same value to the
+    // same address by 64 lanes are one store; the counters below are lane 0's.
+    uint32_t *tlas_stack = reinterpret_cast<uint32_t *>(p) + threadIdx.x, *blas_stack = tlas_stack + (size_t)tlas_levels * EXACT_WB;   // blas: EXACT_STACK entries shared by the wave
+    // the stacks of the ordinary (culled) walk, [level][lane] like everywhere else: the segments of a listed path that
     // are NOT flagged themselves take closest_hit — by the flag rule their result does not depend on the walk — so that a
-    // path costs one or two literal walks (~150 us each) and not eleven
-    uint32_t *fast_stack = reinterpret_cast<uint32_t *>(p) + (size_t)(tlas_levels + blas_levels) * EXACT_WB + (size_t)(threadIdx.x >> 6) * fast_levels * 64u + (threadIdx.x & 63u);
+    // path costs one or two literal walks and not eleven
+    uint32_t *fast_stack = reinterpret_cast<uint32_t *>(p) + (size_t)(tlas_levels + blas_levels) * EXACT_WB + threadIdx.x;
     uint32_t *fast_blas_stack = fast_stack + (size_t)fast_tlas_levels * 64u;
-    for (uint32_t k = blockIdx.x * EXACT_WB + threadIdx.x; k < n; k += gridDim.x * EXACT_WB) {
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
         const float4 e0 = f.ex.list[3 * (size_t)k], e1 = f.ex.list[3 * (size_t)k + 1], e2 = f.ex.list[3 * (size_t)k + 2];
         Ray r{mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y)};
         V3 beta = mk(e1.z, e1.w, e2.x);
         const uint32_t home = __float_as_uint(e2.y);
         int seg = (int)__float_as_uint(e2.z);
         const RngKey key = key_of(f, home);
+        [[maybe_unused]] const unsigned long long p0 = XP_NOW(); [[maybe_unused]] int nseg = 0;
         for (bool first = true;; first = false) {
-            if (!first) atomicAdd(&totals[seg], 1u);                   // the flagged segment itself sits in the wavefront's queue counts
+            if (!first && threadIdx.x == 0) seg_rays[seg]++;           // the flagged segment itself sits in the wavefront's queue counts
             float t = 2e9f; uint32_t obj = MISS, prim = 0;
-            if (first || needs_exact(f.ex, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z))
+            [[maybe_unused]] const unsigned long long w0 = XP_NOW();
+            if (first || needs_exact(f.ex, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z)) {
                 closest_hit_exact(scl, r, key, seg, use_bvh != 0, tlas_stack, blas_stack, t, obj, prim);
-            else {
+                XP_ADD(2, 1); XP_ADD(3, XP_NOW() - w0);
+            } else {
                 bool deferred = false; uint32_t dobj = 0;
                 if (use_bvh) closest_hit<true, false>(sc, r, key, seg, fast_stack, fast_blas_stack, t, obj, prim, deferred, dobj);
                 else closest_hit<false, false>(sc, r, key, seg, fast_stack, fast_blas_stack, t, obj, prim, deferred, dobj);
+                XP_ADD(4, 1); XP_ADD(5, XP_NOW() - w0);
             }
             const uint32_t code = obj == MISS ? MISS : ((obj << sc.prim_bits) | prim);
             Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0);
-            if (!shade_path<false>(sc, f, sc.obj, sc.mat, sc.tex, r, beta, home, t, code, seg, sample_rad, nr, nbeta)) break;
+            [[maybe_unused]] const unsigned long long s0 = XP_NOW();
+            const bool go_on = shade_path<false>(sc, f, sc.obj, sc.mat, sc.tex, r, beta, home, t, code, seg, sample_rad, nr, nbeta);
+            XP_ADD(6, XP_NOW() - s0); nseg++;
+            if (!go_on) break;
             r = nr; beta = nbeta; seg++;
         }
+#ifdef FW_EXACT_PROF
+        { const unsigned long long dt = XP_NOW() - p0; XP_ADD(0, 1); XP_ADD(1, nseg); XP_ADD(7, dt);
+          if (threadIdx.x == 0 && atomicMax(&g_xprof[8], dt) < dt) g_xprof[9] = (unsigned long long)nseg; }
+#endif
     }
+    if (blockIdx.x == 0) XP_ADD(10, 1);
+    __syncthreads();
+    if (threadIdx.x < (uint32_t)MAX_SEGMENTS && seg_rays[threadIdx.x]) atomicAdd(&totals[threadIdx.x], seg_rays[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2655,7 +2746,7 @@ void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPat
 // More than 64 KB of dynamic LDS has to be allowed per kernel AND per device (a process may drive several: fw_render_scene_tiled):
 // true the first time kernel group `which` is about to be launched on the current device.
 static bool lds_attr_needed(int which) {
-    static std::atomic<unsigned char> done[3][64];
+    static std::atomic<unsigned char> done[2][64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
     return done[which][dev].exchange(1) == 0;
@@ -2702,17 +2793,11 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
 void launch_exact_paths(const LaunchCfg &c, const DScene &sc, const DFrame &f, float4 *sample_rad, uint32_t *totals, bool use_bvh) {
-    // stacks sized by the reference trees' depths; the trees themselves in LDS when they fit beside the stacks
-    const uint32_t tl = std::min<uint32_t>(c.ref_tlas_depth + 2u, EXACT_LEVELS), bl = std::min<uint32_t>(c.ref_blas_depth + 2u, EXACT_LEVELS);
-    const uint32_t ftl = use_bvh ? (uint32_t)c.tlas_depth + 1u : 0u, fl = ftl + (uint32_t)c.blas_depth + 1u;     // the ordinary walk's levels (launch_extend)
-    const size_t stacks = (size_t)(tl + bl) * EXACT_WB * 4 + (size_t)(EXACT_WB / 64) * fl * 64 * 4, trees = ((size_t)c.ref_tlas_nodes + c.ref_blas_nodes) * 32;
-    const bool lds_trees = stacks + trees <= 96 * 1024;
-    const size_t lds = stacks + (lds_trees ? trees : 0);
-    if (lds > 48 * 1024 && lds_attr_needed(2)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_exact_paths), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(128 * 1024));
-    // workgroups per CU: 3 x 256 threads are the 3 waves per SIMD its 136 VGPRs allow; fewer when the LDS copy of the trees is big
-    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(3, (150 * 1024) / std::max<size_t>(lds, 1)));
-    hipLaunchKernelGGL(k_exact_paths, dim3((uint32_t)c.n_cus * per_cu), dim3(EXACT_WB), lds, c.stream, sc, f, sample_rad, totals, use_bvh ? 1 : 0,
-                       lds_trees ? 1u : 0u, c.ref_tlas_nodes * 2u, c.ref_blas_nodes * 2u, tl, bl, ftl, fl);
+    // stacks sized by the trees' depths: the reference trees for the literal walk, the walked trees for the ordinary one (launch_extend)
+    const uint32_t tl = std::min<uint32_t>(c.ref_tlas_depth + 2u, EXACT_LEVELS), bl = EXACT_STACK / EXACT_WB;
+    const uint32_t ftl = use_bvh ? (uint32_t)c.tlas_depth + 1u : 0u, fl = ftl + (uint32_t)c.blas_depth + 1u;
+    const size_t lds = (size_t)(tl + bl + fl) * EXACT_WB * 4;
+    hipLaunchKernelGGL(k_exact_paths, dim3((uint32_t)c.n_cus * 16u), dim3(EXACT_WB), lds, c.stream, sc, f, sample_rad, totals, use_bvh ? 1 : 0, tl, bl, ftl, fl);
 }
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment) {
@@ -2745,6 +2830,13 @@ void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else { if (lds_tab) FW_BOUNCE(false, true); else FW_BOUNCE(false, false); }
 #undef FW_BOUNCE
 }
+#ifdef FW_EXACT_PROF
+extern "C" int fw_debug_exact_prof(unsigned long long out[16]) {   // debug builds only; reads and clears the counters
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xprof), sizeof zero) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_xprof), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef FW_TRAV_STATS
 extern "C" int fw_debug_trav_stats(unsigned long long out[8]) {   // debug builds only; reads and clears the counters
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
