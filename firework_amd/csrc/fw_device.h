@@ -89,18 +89,18 @@ struct DScene {
     uint32_t has_mesh;
     uint32_t prim_bits;       // hit code = object << prim_bits | primitive
     const float4 *ref_tlas;   // the REFERENCE trees (host FlatBvh format below: 2 x float4 per node, DFS order), walked only by
-    const float4 *ref_blas;   // k_exact_paths; ref_blas holds every mesh's tree, child indices relative to the mesh's first node
+    const float4 *ref_blas;   // k_extend_exact; ref_blas holds every mesh's tree, child indices relative to the mesh's first node
     const uint32_t *obj_ref_blas;   // per object: first node of its mesh's reference tree in ref_blas (meshes and media around meshes)
     uint32_t n_hoisted;       // objects kept OUT of the walked TLAS because nearly every ray meets their box (part2's fog sphere
     uint32_t hoisted[4];      // around the whole scene): tested for every ray, wave-uniformly, before the walk (hoisted_hits)
     DEnv env;
 };
 
-// ---- the exact walk (k_exact_paths).  A ray whose result depends on HOW the trees are walked — not on where it goes — is
-// flagged when it is made (k_raygen / k_shade): its path LEAVES the wavefront there (k_shade skips its slot from then on) and is
-// finished, segment by segment, by one kernel per batch that traces every ray with the literal algorithm of bvh.rs:115-151 over
+// ---- the exact walk (k_extend_exact).  A ray whose result depends on HOW the trees are walked — not on where it goes — is
+// flagged when it is made (k_raygen / k_shade): its queue slot goes on the list of its segment, and after the segment's ordinary
+// k_extend one more kernel traces the listed rays with the literal algorithm of bvh.rs:115-151 over
 // the reference's own trees (median split, node boxes, DoubleLeaf = both items behind one box, both children always, no
-// culling) and shades with k_shade's own code.  Two classes, both found by tools/diverge.py:
+// culling) and writes its hit record over the ordinary one.  Two classes, both found by tools/diverge.py:
 //   mode & 1  ill-conditioned triangle shears (scenes with meshes): mesh.rs:147-162 permutes the axes by the SIGNED largest
 //             direction component (util.rs:104-118), so a ray like (-0.88, 0.00016, -0.41) divides by 0.00016: shear factors
 //             of ~5000, edge functions that are rounding noise, "hits" whose t lies outside the triangle's box.  Which of
@@ -116,11 +116,9 @@ struct DExact {
     float frames[4][9];
     float far_c[3], far_r;        // centre of the small-object cluster, distance beyond which an origin is "far"
     float box_lo[3], box_hi[3];   // the cluster's box, inflated
-    uint32_t *bits;               // one bit per path slot of the NEXT segment's queue: "this path has left the wavefront" (k_shade skips
-                                  // it and clears the bit); zeroed per batch
-    float4 *list;                 // the paths that left: 3 x float4 each — (o.xyz d.x) (d.y d.z beta.r beta.g) (beta.b, bits home slot, bits segment, -)
-    uint32_t *list_count;         // entries of `list` (one device-wide counter per batch, bumped once per wave and chunk that flags anything)
-    uint32_t list_cap;            // = the batch's paths: a path is flagged at most once
+    uint32_t *slots[2];           // the flagged rays' queue slots: list of segment s in slots[s & 1] (filled by k_raygen / k_shade(s-1), read by k_extend_exact(s))
+    uint32_t *count;              // [MAX_SEGMENTS + 1] entries per list, zeroed per batch; bumped once per wave and chunk that flags anything
+    uint32_t cap;                 // = the batch's paths
 };
 
 struct DCamera {   // camera.rs:7-16
@@ -198,7 +196,7 @@ struct LaunchCfg {
     uint32_t n_defer;     // linear scan: the scene's last n_defer (1 or 2) objects are plain Rect3d boxes handled by k_extend_linear_defer; 0: k_extend_linear
     bool lds_trees;       // walk trees that fit out of LDS (k_blas_lds); FIREWORK_NO_LDS_TREES=1 switches it off
     int shade_mode;       // k_shade: 0 everything in line, 1 the scene has no expensive material / environment (the cheap loop alone), 2 expensive paths go through a list (FIREWORK_SHADE_LIST=1: measured slower, kept for A/B)
-    uint32_t ref_tlas_nodes, ref_blas_nodes, ref_tlas_depth, ref_blas_depth;   // the reference trees k_exact_paths walks (nodes of 32 B)
+    uint32_t ref_tlas_nodes, ref_blas_nodes, ref_tlas_depth, ref_blas_depth;   // the reference trees k_extend_exact walks (nodes of 32 B)
     bool tlas_refill;     // refilling walks: k_extend_tlas (no meshes) / k_extend_tlas_park + k_blas (meshes); FIREWORK_TLAS_REFILL=0: the chunked k_extend_bvh
 };
 constexpr size_t LDS_TREE_LIMIT = 160 * 1024;   // the whole LDS of a CU: one workgroup of the LDS-resident walks per CU
@@ -206,7 +204,7 @@ constexpr size_t LDS_TABLE_LIMIT = 16 * 1024;   // object+material+texture table
 
 void launch_raygen(const LaunchCfg &, const DCamera &, const DFrame &, DPaths out, float4 *sample_rad, uint32_t n_paths);
 void launch_extend(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, float2 *hits, int segment, bool use_bvh, DPark park);
-void launch_exact_paths(const LaunchCfg &, const DScene &, const DFrame &, float4 *sample_rad, uint32_t *totals, bool use_bvh);
+void launch_extend_exact(const LaunchCfg &, const DScene &, const DFrame &, const DPaths &in, float2 *hits, int segment, bool use_bvh);
 void launch_shade(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment);
 void launch_bounce(const LaunchCfg &, const DScene &, const DFrame &, DPaths in, DPaths out, float4 *sample_rad, int segment,

@@ -26,6 +26,7 @@
 #include "fw_device.h"
 #include "fw_libm.h"
 #include <atomic>
+#include <type_traits>
 
 namespace fw {
 
@@ -230,8 +231,18 @@ __device__ __forceinline__ bool ill_direction(float dx, float dy, float dz) {
     const float am = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
     return fabsf(dk) < am * (1.0f / 1024.0f);
 }
+// A ray with a NaN in it passes every box (the slab test's min / max drop NaNs) and "hits" triangles with a NaN t that no comparison
+// rejects (mesh.rs:164-177) and that `!(best < t)` lets replace and be replaced: its result depends on the order of the tests like
+// nothing else, and an ordinary walk spends a millisecond on it, one lane through a whole tree while its launch waits (suzanne:
+// one such path made four k_blas_lds launches of ~150 us last ~1 ms each).  With the exact walk on it is flagged (needs_exact)
+// and the ordinary walks leave it out (skip_ray).  (inf - inf counts: no harm.)
+__device__ __forceinline__ bool nan_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
+    const float s = ((ox + oy) + oz) + ((dx + dy) + dz);
+    return s != s;
+}
 __device__ __forceinline__ bool needs_exact(const DExact &ex, float ox, float oy, float oz, float dx, float dy, float dz) {
     if (ex.mode & 4u) return true;
+    if (nan_ray(ox, oy, oz, dx, dy, dz)) return true;
     if (ex.mode & 1u) {
         if (ill_direction(dx, dy, dz)) return true;
         for (uint32_t k = 0; k < ex.n_frames; k++) {            // inv_rotation_mat * d = rows of rotation_mat as columns (rot_inv)
@@ -254,23 +265,20 @@ __device__ __forceinline__ bool needs_exact(const DExact &ex, float ox, float oy
     }
     return false;
 }
-// The flagged paths of one wave-chunk leave the wavefront: their slot's bit is set (k_shade will skip the slot) and path state +
-// ray go to the batch's list for k_exact_paths.  Called by every lane of the wave (fl = false where there is nothing to send):
-// one device-wide atomic per wave and chunk that flags anything.
-__device__ __forceinline__ void send_exact(const DExact &ex, bool fl, uint32_t slot, V3 o, V3 d, V3 beta, uint32_t home, int segment) {
+template <class R>
+__device__ __forceinline__ bool skip_ray(const DExact &ex, const R &r) { return ex.mode != 0u && nan_ray(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z); }
+// The flagged rays of one wave-chunk go on the list of their segment (DExact): k_extend_exact walks them again, literally, after
+// the ordinary k_extend and before k_shade.  Called by every lane of the wave (fl = false where there is nothing to flag): one
+// device-wide atomic per wave and chunk that flags anything.  slot: the ray's slot in the queue of `segment`.
+__device__ __forceinline__ void flag_exact(const DExact &ex, bool fl, uint32_t slot, int segment) {
     const unsigned long long m = __ballot(fl);
     if (!m) return;
     const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)m) - 1u;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
     uint32_t at = 0;
-    if (lane == leader) at = atomicAdd(ex.list_count, (uint32_t)__popcll(m));
+    if (lane == leader) at = atomicAdd(&ex.count[segment], (uint32_t)__popcll(m));
     at = (uint32_t)__shfl((int)at, (int)leader) + rank;
-    if (fl && at < ex.list_cap) {
-        atomicOr(&ex.bits[slot >> 5], 1u << (slot & 31u));
-        float4 *e = ex.list + 3 * (size_t)at;
-        e[0] = make_float4(o.x, o.y, o.z, d.x); e[1] = make_float4(d.y, d.z, beta.x, beta.y);
-        e[2] = make_float4(beta.z, __uint_as_float(home), __uint_as_float((uint32_t)segment), 0.f);
-    }
+    if (fl && at < ex.cap) ex.slots[segment & 1][at] = slot;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(WB) void k_raygen(DCamera cam, DFrame f, DPaths out
             }
             fl = f.ex.mode && needs_exact(f.ex, o.x, o.y, o.z, d.x, d.y, d.z);
         }
-        if (f.ex.mode) send_exact(f.ex, fl, slot, o, d, mk(1.f, 1.f, 1.f), slot, 0);     // a camera path: throughput 1, home slot = its slot
+        if (f.ex.mode) flag_exact(f.ex, fl, slot, 0);
         produced += min(64u, n_paths - id0);
     }
     if (lane == 0) q.wcount[w] = produced;                                    // segment 0 queue length of this wave
@@ -727,49 +735,59 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
     return have;
 }
 
-// The literal mesh walk of the reference (bvh.rs:115-151 over mesh.rs's Triangle items) for k_exact_paths: the mesh's own
+// The literal mesh walk of the reference (bvh.rs:115-151 over mesh.rs's Triangle items) for k_extend_exact: the mesh's own
 // median-split tree, a node's items tested whenever the ray passes the NODE's box (a DoubleLeaf holds two behind one box),
 // both children always, nothing culled; the smaller t wins, a tie goes to the later item (`if lh.t < rh.t {lh} else {rh}`).
 // ref_root = first node of the mesh's tree in sc.ref_blas (child indices are relative to it).
 constexpr int EXACT_LEVELS = 40;    // a median-split tree over N items is ceil(log2 N) deep: < 2^32 items
-constexpr int EXACT_STACK = 512;    // entries of the stack the 64 lanes of a wave share in hit_mesh_exact
-constexpr int EXACT_WB = 64;        // threads per workgroup of k_exact_paths: its stacks are [level][EXACT_WB] columns in LDS.  Single waves with a few KB of LDS:
-                                    // they have to fit on a CU next to the LDS-resident walks' 137-150 KB (with 256 threads and the reference trees in LDS they did not,
-                                    // and the other batch's k_blas_lds waited for them: suzanne 80 -> 99 ms)
-// The reference's walk over one mesh, node by node in its own order (bvh.rs:92-131): every lane of the wave the same walk (see
-// hit_mesh_exact, which calls this when the order of the tests matters).  ws: the wave's shared stack.
-__device__ __forceinline__ bool hit_mesh_exact_serial(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
-                                                   uint32_t *ws, float &t_out, uint32_t &tri_out) {
-    const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+constexpr int EXACT_STACK = 512;    // entries of the stack the 64 lanes of a wave share in hit_mesh_exact_wave
+constexpr uint32_t EXACT_WAVE_RAYS = 8;   // k_extend_exact: one ray per wave while the list is at most this many rays per wave of the launch
+constexpr int EXACT_WB = 64;        // threads per workgroup of k_extend_exact (one wave): its stacks are [level][EXACT_WB] columns in LDS, a few KB that fit
+                                    // on a CU next to the LDS-resident walks' 137-150 KB of the other batch in flight
+// The reference's walk over one mesh (bvh.rs:92-131), one ray per LANE: k_extend_exact's form for long lists.  Never narrows
+// its interval, `!(best < t)` replaces.  stack: this lane's column of an LDS array [level][EXACT_WB].
+__device__ __forceinline__ bool hit_mesh_exact_lane(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
+                                                    uint32_t *stack, float &t_out, uint32_t &tri_out) {
+    const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));      // aabb.rs:33: 1.0 / r.direction()[a]
     const TriRay tr = make_triray(r);
     const float4 *nodes = sc.ref_blas + 2 * (size_t)ref_root;
     int sp = 0;
     uint32_t cur = 0; bool have = false; float best = tmax; uint32_t best_tri = 0;
-    for (;;) {
-        const float4 lo = nodes[2 * (size_t)cur], hi = nodes[2 * (size_t)cur + 1];
-        const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
-        if (hit_aabb(lo, hi, r.o, inv, tmin, tmax)) {
-            if ((A >> 30) == 0u) { if (sp < EXACT_LEVELS) { ws[sp] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }     // Branch: left = next node, right later
-            const bool two = (A >> 30) == NODE_DOUBLE;
-            for (uint32_t k = 0; k < (two ? 2u : 1u); k++) {
-                const uint32_t i = k ? B : (A & NODE_MASK);
-                const float4 *pt = sc.tri + 3 * (size_t)(tri_base + i);
-                const float4 a = pt[0], b = pt[1], c = pt[2];
-                float t, u0, u1, u2;
-                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, tmin, tmax, t, u0, u1, u2))
-                    if (!have || !(best < t)) { have = true; best = t; best_tri = i; }
+    // while-while: every lane first goes down to its next leaf node (or runs out of tree); only then do the lanes test their
+    // triangles, together — with the leaf test inside the node loop every step of the wave paid for a triangle fetch from L2
+    for (bool more = true; more;) {
+        uint32_t A = 0, B = 0; bool leaf = false;
+        for (;;) {
+            const float4 lo = nodes[2 * (size_t)cur], hi = nodes[2 * (size_t)cur + 1];
+            A = __float_as_uint(lo.w); B = __float_as_uint(hi.w);
+            if (hit_aabb(lo, hi, r.o, inv, tmin, tmax)) {
+                if ((A >> 30) == 0u) { if (sp < EXACT_LEVELS) { stack[sp * EXACT_WB] = A & NODE_MASK; sp++; } cur = cur + 1u; continue; }     // Branch: left = next node, right later
+                leaf = true; break;
             }
+            if (sp == 0) { more = false; break; }
+            sp--; cur = stack[sp * EXACT_WB];
         }
-        if (sp == 0) break;
-        sp--; cur = ws[sp];
+        if (leaf) {
+            const bool two = (A >> 30) == NODE_DOUBLE;
+            const uint32_t i0 = A & NODE_MASK, i1 = two ? B : i0;
+            const float4 *p0 = sc.tri + 3 * (size_t)(tri_base + i0), *p1 = sc.tri + 3 * (size_t)(tri_base + i1);
+            const float4 a0 = p0[0], b0 = p0[1], c0 = p0[2], a1 = p1[0], b1 = p1[1], c1 = p1[2];     // both triangles of a DoubleLeaf requested at once
+            float t, u0, u1, u2;
+            if (hit_triangle(mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z), tr, tmin, tmax, t, u0, u1, u2))
+                if (!have || !(best < t)) { have = true; best = t; best_tri = i0; }
+            if (two && hit_triangle(mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z), tr, tmin, tmax, t, u0, u1, u2))
+                if (!have || !(best < t)) { have = true; best = t; best_tri = i1; }
+            if (sp == 0) more = false;
+            else { sp--; cur = stack[sp * EXACT_WB]; }
+        }
     }
     t_out = best; tri_out = best_tri;
     return have;
 }
 
-__device__ __forceinline__ bool hit_mesh_exact(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
+__device__ __forceinline__ bool hit_mesh_exact_wave(const DScene &sc, uint32_t ref_root, uint32_t tri_base, const Ray &r, float tmin, float tmax,
                                uint32_t *stack, float &t_out, uint32_t &tri_out) {
-    // ONE RAY PER WAVE: the 64 lanes hold the same ray (k_exact_paths runs one path per wave, every lane the same instructions
+    // ONE RAY PER WAVE: the 64 lanes hold the same ray (k_extend_exact's form for short lists: every lane the same instructions
     // on the same values) and share this walk.  The reference's walk (bvh.rs:92-131) never narrows its interval: it tests every
     // node whose ancestors' boxes the ray hits with the caller's (tmin, tmax), and of the triangles hit it returns the smallest
     // t, the LATER one in its depth-first order on a tie (`!(best < t)` replaces).  Neither the set of nodes nor that choice
@@ -778,68 +796,79 @@ __device__ __forceinline__ bool hit_mesh_exact(const DScene &sc, uint32_t ref_ro
     // node's index.  A walk is then ~depth rounds of one L2 latency each instead of one latency per node visited (60-150 us),
     // and the lanes of a wave no longer wait for each other's different paths.
     // One case does depend on the order: mesh.rs:164-177 lets a NaN t through (no comparison rejects it), and `!(best < t)` then
-    // replaces whatever came before and is replaced by whatever comes next.  A wave that meets one walks again, in order.
+    // replaces whatever came before and is replaced by whatever comes next — so the reference returns what its rule makes of
+    // the hits BEHIND the last NaN one in depth-first order, or that NaN hit if none follows.  A wave that meets a NaN t takes
+    // the largest position of one and walks once more, counting only hits behind it.
     const uint32_t lane = threadIdx.x & 63u;
     const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));      // aabb.rs:33: 1.0 / r.direction()[a]
     const TriRay tr = make_triray(r);
     const float4 *nodes = sc.ref_blas + 2 * (size_t)ref_root;
     uint32_t *ws = stack - lane;                                         // the wave's EXACT_STACK entries
-    bool have = false, nan_t = false; float best = tmax; uint32_t best_tri = 0, best_pos = 0;
-    uint32_t sp = 1;                                                     // wave-uniform
-    if (lane == 0) ws[0] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    while (sp > 0u) {
-        // as many nodes as fit: a round pops k and pushes at most 2k; with little room left the wave goes node by node, which
-        // needs at most one more entry per level of the tree below the node (EXACT_LEVELS, kept free)
-        const int room = EXACT_STACK - EXACT_LEVELS - 8 - (int)sp;
-        uint32_t k = min(64u, sp);
-        if ((int)k > room) k = (uint32_t)max(1, room);
-        const bool active = lane < k;
-        const uint32_t node = active ? ws[sp - 1u - lane] : 0u;
-        sp -= k;
-        float4 lo = make_float4(0, 0, 0, 0), hi = lo;
-        if (active) { lo = nodes[2 * (size_t)node]; hi = nodes[2 * (size_t)node + 1]; }
-        const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
-        const bool hitb = active && hit_aabb(lo, hi, r.o, inv, tmin, tmax);
-        const bool branch = hitb && (A >> 30) == 0u;
-        const unsigned long long m = __ballot(branch);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");           // the pops above before the pushes below
-        if (branch) {
-            const uint32_t at = sp + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            ws[at] = A & NODE_MASK; ws[at + 1u] = node + 1u;
-        }
-        sp += 2u * (uint32_t)__popcll(m);
+    bool have = false; float best = tmax; uint32_t best_tri = 0, best_pos = 0;
+    int after = -1;                                                      // only hits at positions > after count (second pass)
+    int nan_pos = -1; uint32_t nan_tri = 0, nan_bits = 0;                // the last NaN hit
+    for (bool second = false;; second = true) {
+        have = false; best = tmax; best_tri = 0; best_pos = 0;
+        uint32_t sp = 1;                                                 // wave-uniform
+        if (lane == 0) ws[0] = 0u;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (hitb && !branch) {
-            const bool two = (A >> 30) == NODE_DOUBLE;
-            const uint32_t i0 = A & NODE_MASK, i1 = two ? B : i0;
-            const float4 *p0 = sc.tri + 3 * (size_t)(tri_base + i0), *p1 = sc.tri + 3 * (size_t)(tri_base + i1);
-            const float4 a0 = p0[0], b0 = p0[1], c0 = p0[2], a1 = p1[0], b1 = p1[1], c1 = p1[2];     // both triangles of a DoubleLeaf requested at once
-            float t, u0, u1, u2;
-            if (hit_triangle(mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z), tr, tmin, tmax, t, u0, u1, u2)) {
-                nan_t |= t != t;
-                if (!have || t < best || (t == best && 2u * node > best_pos)) { have = true; best = t; best_tri = i0; best_pos = 2u * node; }
+        while (sp > 0u) {
+            // as many nodes as fit: a round pops k and pushes at most 2k; with little room left the wave goes node by node, which
+            // needs at most one more entry per level of the tree below the node (EXACT_LEVELS, kept free)
+            const int room = EXACT_STACK - EXACT_LEVELS - 8 - (int)sp;
+            uint32_t k = min(64u, sp);
+            if ((int)k > room) k = (uint32_t)max(1, room);
+            const bool active = lane < k;
+            const uint32_t node = active ? ws[sp - 1u - lane] : 0u;
+            sp -= k;
+            float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+            if (active) { lo = nodes[2 * (size_t)node]; hi = nodes[2 * (size_t)node + 1]; }
+            const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
+            const bool hitb = active && hit_aabb(lo, hi, r.o, inv, tmin, tmax);
+            const bool branch = hitb && (A >> 30) == 0u;
+            const unsigned long long m = __ballot(branch);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");       // the pops above before the pushes below
+            if (branch) {
+                const uint32_t at = sp + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                ws[at] = A & NODE_MASK; ws[at + 1u] = node + 1u;
             }
-            if (two && hit_triangle(mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z), tr, tmin, tmax, t, u0, u1, u2)) {
-                nan_t |= t != t;
-                if (!have || t < best || (t == best && 2u * node + 1u > best_pos)) { have = true; best = t; best_tri = i1; best_pos = 2u * node + 1u; }
+            sp += 2u * (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (hitb && !branch) {
+                const bool two = (A >> 30) == NODE_DOUBLE;
+                const uint32_t i0 = A & NODE_MASK, i1 = two ? B : i0;
+                const float4 *p0 = sc.tri + 3 * (size_t)(tri_base + i0), *p1 = sc.tri + 3 * (size_t)(tri_base + i1);
+                const float4 a0 = p0[0], b0 = p0[1], c0 = p0[2], a1 = p1[0], b1 = p1[1], c1 = p1[2];     // both triangles of a DoubleLeaf requested at once
+                auto take = [&](float t, uint32_t tri, uint32_t pos) {
+                    if (t != t) { if ((int)pos > nan_pos) { nan_pos = (int)pos; nan_tri = tri; nan_bits = __float_as_uint(t); } }
+                    else if ((int)pos > after && (!have || t < best || (t == best && pos > best_pos))) { have = true; best = t; best_tri = tri; best_pos = pos; }
+                };
+                float t, u0, u1, u2;
+                if (hit_triangle(mk(a0.x, a0.y, a0.z), mk(b0.x, b0.y, b0.z), mk(c0.x, c0.y, c0.z), tr, tmin, tmax, t, u0, u1, u2)) take(t, i0, 2u * node);
+                if (two && hit_triangle(mk(a1.x, a1.y, a1.z), mk(b1.x, b1.y, b1.z), mk(c1.x, c1.y, c1.z), tr, tmin, tmax, t, u0, u1, u2)) take(t, i1, 2u * node + 1u);
             }
         }
+        if (second || __ballot(nan_pos >= 0) == 0ull) break;
+        for (int d = 1; d < 64; d <<= 1) {        // the last NaN hit of the wave
+            const int op = __shfl_xor(nan_pos, d); const uint32_t otri = (uint32_t)__shfl_xor((int)nan_tri, d), ob = (uint32_t)__shfl_xor((int)nan_bits, d);
+            if (op > nan_pos) { nan_pos = op; nan_tri = otri; nan_bits = ob; }
+        }
+        after = nan_pos;
     }
-    if (__ballot(nan_t) != 0ull) return hit_mesh_exact_serial(sc, ref_root, tri_base, r, tmin, tmax, ws, t_out, tri_out);
     for (int d = 1; d < 64; d <<= 1) {            // butterfly: every lane ends with the wave's winner
         const bool oh = __shfl_xor((int)have, d) != 0;
         const float ot = __shfl_xor(best, d);
         const uint32_t otri = (uint32_t)__shfl_xor((int)best_tri, d), opos = (uint32_t)__shfl_xor((int)best_pos, d);
         if (oh && (!have || ot < best || (ot == best && opos > best_pos))) { have = true; best = ot; best_tri = otri; best_pos = opos; }
     }
+    if (!have && after >= 0) { t_out = __uint_as_float(nan_bits); tri_out = nan_tri; return true; }
     t_out = best; tri_out = best_tri;
     return have;
 }
 
 // shape dispatch in object space.  prim: rect3d face / mesh triangle, else 0.  EXACT: a mesh takes the literal reference walk
-// and aux0 is its reference tree's first node (k_exact_paths).
-template <bool EXACT = false>
+// and aux0 is its reference tree's first node (k_extend_exact; 1: one ray per lane, 2: per wave).
+template <int EXACT = 0>
 __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float4 q3, float4 q4, uint32_t aux0, uint32_t aux1,
                                           const Ray &r, float tmin, float tmax, uint32_t *stack_base, float &t, uint32_t &prim) {
     prim = 0;
@@ -847,7 +876,8 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
     case 0: return hit_sphere(q3.x, r, tmin, tmax, t);
     case 1: case 2: case 3: return hit_rect_kind(kind, q3, q4, r, tmin, tmax, t);
     case 4: return hit_rect3d(q3, q4, r, tmin, tmax, t, prim);
-    case 5: if (EXACT) return hit_mesh_exact(sc, aux0, aux1, r, tmin, tmax, stack_base, t, prim);
+    case 5: if (EXACT == 2) return hit_mesh_exact_wave(sc, aux0, aux1, r, tmin, tmax, stack_base, t, prim);
+            if (EXACT == 1) return hit_mesh_exact_lane(sc, aux0, aux1, r, tmin, tmax, stack_base, t, prim);
             return hit_mesh(sc, aux0, aux1, r, tmin, tmax, tmax, stack_base, t, prim);
     case 7: return hit_cone(q3.x, q3.y, r, tmin, tmax, t);
     case 8: return hit_cylinder(q3.x, q3.y, q3.z, r, tmin, tmax, t);
@@ -857,7 +887,7 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
 }
 
 // objects/volume.rs:56-82
-template <bool EXACT = false>
+template <int EXACT = 0>
 __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const Ray &r, float tmin, float tmax,
                                            uint32_t *stack_base, const RngKey &key, uint32_t segment, uint32_t obj_index, float &t_out) {
     const float FMAX = 3.40282347e+38f;
@@ -881,7 +911,7 @@ __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const
 // RenderObjectInternal::hit up to the object-space t (the world-space point/normal are rebuilt in k_shade)
 // MEDIUM = false: the caller's scene holds no ConstantMedium (k_extend_linear_defer: the host checks), so the medium's code —
 // its double-precision log10 costs registers even where it never runs — is compiled out
-template <bool MEDIUM = true, bool EXACT = false>
+template <bool MEDIUM = true, int EXACT = 0>
 __device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint32_t obj_index, const Ray &world, float tmin,
                                            float tmax, uint32_t *stack_base, const RngKey &key, uint32_t segment, float &t, uint32_t &prim) {
     Ray r = to_object_space(o, world);
@@ -1222,7 +1252,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                         wo = r.o; wd = r.d;
                         inv = mk(fdiv(1.f, wd.x), fdiv(1.f, wd.y), fdiv(1.f, wd.z));
                         path_id = __float_as_uint(rs);
-                        cur = sc.tlas_root; st.sp = 0;
+                        cur = skip_ray(f.ex, r) ? REF_DONE : sc.tlas_root; st.sp = 0;      // a NaN ray's record comes from k_extend_exact
                         have = false; best_t = TMAX; best_obj = MISS; best_prim = 0; deferred = false; deferred_obj = 0;
                         if (!PARK && sc.n_hoisted) {      // objects are hoisted only in scenes without meshes
                             RngKey hkey{0, 0, 0};
@@ -1309,7 +1339,8 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
             Ray r = make_ray(ra, rb, f, segment);
             RngKey key{0, 0, 0};
             if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
-            closest_hit<USE_BVH, USE_BVH>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj);
+            if (!skip_ray(f.ex, r))     // a NaN ray's record comes from k_extend_exact
+                closest_hit<USE_BVH, USE_BVH>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj);
             if (!USE_BVH && f.hit4) reinterpret_cast<uint32_t *>(hits)[i] = __float_as_uint(pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y);   // the code alone: k_shade recomputes t
             else if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
         }
@@ -1373,7 +1404,8 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVE
             RngKey key{0, 0, 0};
             if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
             const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
-            for (uint32_t k = 0; k < sc.n_objects; k++) {
+            const uint32_t n_obj = skip_ray(f.ex, r) ? 0u : sc.n_objects;      // a NaN ray's record comes from k_extend_exact
+            for (uint32_t k = 0; k < n_obj; k++) {
                 const float4 lo = sc.obj_cull[2 * (size_t)k], hi = sc.obj_cull[2 * (size_t)k + 1];   // the leaf's box in the walked tree
                 float entry;
                 if (!hit_aabb_entry(lo, hi, r.o, inv, TMIN, TMAX, entry) || entry > cull_bound(have ? best_t : TMAX)) continue;
@@ -1826,7 +1858,7 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
                     wo = r.o; wd = r.d;
                     inv = rinv;
                     path_id = __float_as_uint(rs);
-                    cur = sc.tlas_root; st.sp = 0;
+                    cur = skip_ray(f.ex, r) ? REF_DONE : sc.tlas_root; st.sp = 0;          // a NaN ray's record comes from k_extend_exact
                     have = robj != MISS; best_t = rt; best_obj = robj; best_prim = rprim;     // what the hoisted objects gave (prep_block)
                 }
                 c_pos += take;
@@ -1867,10 +1899,11 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
 
 // ------------------------------------------------------------------------------------------------
 // K2-exact  closest_hit_exact: one ray by the literal algorithm of the reference — scene.rs:137-149 (linear) or bvh.rs:115-151
-// over the reference's OWN trees (use_bvh).  Used by k_exact_paths (behind k_shade below), which finishes the paths that have
-// left the wavefront (DExact, fw_device.h).  Written for clarity, not speed: nodes through generic pointers (LDS when the trees
-// fit, else L2), stacks in LDS.  With FIREWORK_EXACT_ALL=1 every path takes it: the renderer then IS the reference's traversal.
+// over the reference's OWN trees (use_bvh).  Used by k_extend_exact (behind k_shade below) for the rays on a segment's list
+// (DExact, fw_device.h).  Nodes from L2, stacks in LDS.  With FIREWORK_EXACT_ALL=1 every ray takes it: the renderer then IS the
+// reference's traversal.
 // ------------------------------------------------------------------------------------------------
+template <int EXACT>   // 1: one ray per lane, 2: one ray per wave (hit_mesh_exact_lane / _wave)
 __device__ __forceinline__ void closest_hit_exact(const DScene &sc, const Ray &r, const RngKey &key, int segment, bool use_bvh, uint32_t *tlas_stack,
                                                   uint32_t *blas_stack, float &best_t, uint32_t &best_obj, uint32_t &best_prim) {
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
@@ -1879,14 +1912,14 @@ __device__ __forceinline__ void closest_hit_exact(const DScene &sc, const Ray &r
         for (uint32_t k = 0; k < sc.n_objects; k++) {
             const Obj o = load_obj(sc.obj, k);
             float t; uint32_t prim;
-            if (hit_object<true, true>(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+            if (hit_object<true, EXACT>(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
         }
         return;
     }
     const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
     int sp = 0;
     uint32_t cur = 0; bool have = false;
-    for (bool more = true; more;) {          // while-while, like hit_mesh_exact: down to the next leaf node first, then the object tests together
+    for (bool more = true; more;) {          // while-while, like hit_mesh_exact_lane: down to the next leaf node first, then the object tests together
         uint32_t A = 0, B = 0; bool leaf = false;
         for (;;) {
             const float4 lo = sc.ref_tlas[2 * (size_t)cur], hi = sc.ref_tlas[2 * (size_t)cur + 1];
@@ -1903,7 +1936,7 @@ __device__ __forceinline__ void closest_hit_exact(const DScene &sc, const Ray &r
                 const uint32_t item = k ? B : (A & NODE_MASK);
                 const Obj o = load_obj(sc.obj, item);
                 float t; uint32_t prim;
-                if (hit_object<true, true>(sc, o, item, r, TMIN, TMAX, blas_stack, key, segment, t, prim))
+                if (hit_object<true, EXACT>(sc, o, item, r, TMIN, TMAX, blas_stack, key, segment, t, prim))
                     if (!have || !(best_t < t)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
             }
             if (sp == 0) more = false;
@@ -2302,8 +2335,8 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
             qst(&out.ray_b[dst], make_float2(nr.d.y, nr.d.z));
             qst(&out.state[dst], make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id)));
         }
-        if (f.ex.mode)     // a new ray whose result depends on traversal order: its path leaves the wavefront here (DExact)
-            send_exact(f.ex, alive && needs_exact(f.ex, nr.o.x, nr.o.y, nr.o.z, nr.d.x, nr.d.y, nr.d.z), base + out_n + rank, nr.o, nr.d, nbeta, path_id, segment + 1);
+        if (f.ex.mode)     // a new ray whose result depends on traversal order: k_extend_exact walks it literally (DExact)
+            flag_exact(f.ex, alive && needs_exact(f.ex, nr.o.x, nr.o.y, nr.o.z, nr.d.x, nr.d.y, nr.d.z), base + out_n + rank, segment + 1);
         out_n += (uint32_t)__popcll(mask);
     };
     auto load_hit = [&](uint32_t idx) { return f.hit4 ? make_float2(0.f, __uint_as_float(reinterpret_cast<const uint32_t *>(hits)[idx])) : qld(&hits[idx]); };
@@ -2330,17 +2363,7 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
         if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); st_n = load_state(in, i + 64u, segment); hr_n = load_hit(i + 64u); }
         bool alive = false, later = false;
         Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
-        bool gone = false;                                   // this slot's path has left the wavefront (k_exact_paths finishes it)
-        if (f.ex.mode) {
-            const uint32_t wd = (j < n) ? f.ex.bits[i >> 5] : 0u;
-            gone = ((wd >> (i & 31u)) & 1u) != 0u;
-            const unsigned long long gm = __ballot(gone);      // consumed: cleared with an atomic AND, so that a flag this wave's own
-            if (gm && lane < 2u) {                              // compaction sets in the same word afterwards can never be lost
-                const uint32_t m = lane ? (uint32_t)(gm >> 32) : (uint32_t)gm;
-                if (m) atomicAnd(&f.ex.bits[((base + c0) >> 5) + lane], ~m);
-            }
-        }
-        if (j < n && !gone) {
+        if (j < n) {
             Ray r = make_ray(ra, rb, f, segment);
             V3 beta = mk(st.x, st.y, st.z);
             path_id = __float_as_uint(st.w);
@@ -2363,91 +2386,46 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
 }
 
-#ifdef FW_EXACT_PROF
-// debug builds (-DFW_EXACT_PROF, tools/exact_prof.py): where k_exact_paths' time goes.  [0] paths [1] segments [2] literal walks
-// [3] clocks in literal walks [4] ordinary walks [5] clocks in them [6] clocks shading [7] clocks of all paths [8] longest path
-// [9] its segments [10] kernel launches (s_memrealtime: 100 MHz)
-__device__ unsigned long long g_xprof[16];
-#define XP_ADD(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_xprof[k], (unsigned long long)(v)); } while (0)
-#define XP_NOW() wall_clock64()
-#else
-#define XP_ADD(k, v) do { } while (0)
-#define XP_NOW() 0ull
-#endif
 // ------------------------------------------------------------------------------------------------
-// K-exact  k_exact_paths: the paths that left the wavefront (DExact), finished here — one launch per batch, after its last k_shade.
+// K-exact  k_extend_exact: the rays whose result depends on how the trees are walked (DExact), walked the reference's way.
 //
-// Each lane takes one listed path and follows it to its end: closest_hit_exact for every remaining segment (the literal walk is
-// the reference's semantics for ANY ray, so a path that needed it once keeps it), k_shade's own shade_path for the hit, the
-// radiance deposited at the path's home slot like every other path's.  Its rays beyond the one it was flagged with are added to
-// the batch's per-depth ray counts.
-// (The first two versions traced the flagged rays of every SEGMENT in their own launch and handed the hits back to k_shade:
-// one walk without culling takes ~150 us — a wave's lanes alternate between node steps and triangle tests — and a launch lasts
-// as long as its longest walk, 22 launches per batch: suzanne @64 spp 9.7 -> 14.7 ms for 0.07 % of its rays, whether the trees sat
-// in L2 or in LDS.  Here that latency is paid once per batch and overlaps the other batch's kernels.)
-// Dynamic LDS: [TLAS stacks: tlas_levels x 64 u32][BLAS stacks: blas_levels x 64 u32][the ordinary walk's stacks: fast_levels x 64 u32].
-// (The reference trees in LDS instead of L2 changed nothing that could be measured: a literal walk is long because it is literal.)
+// One launch per segment, after the ordinary k_extend (and k_blas) of the segment and before its k_shade: for every slot on the
+// segment's list, closest_hit_exact over the reference's own trees, the hit record written over the ordinary one.  The rays stay
+// in the wavefront — queue, shading, compaction and ray counts are everybody's — and a path pays for the literal walk only in
+// the segments that need it (one in 2.75 on suzanne).
+// A walk without culling is long (~150 us for a lane, whose wave alternates between node steps and triangle tests), and a launch
+// lasts as long as its longest wave.  So a SHORT list (most of them: a few hundred rays per segment beyond the camera rays) is
+// walked one ray per wave, the lanes sharing the walk (hit_mesh_exact_wave, ~25-50 us), and only a list too long for that
+// (the flagged camera rays of a big batch) one ray per lane.
+// (Earlier forms this round: a scan kernel + an exact kernel per segment, one ray per lane: suzanne @64 spp 9.7 -> 14.7 ms for
+// 0.07 % of its rays.  Then the flagged paths LEFT the wavefront and one kernel per batch finished them, first one path per
+// lane, then one per wave (k_exact_paths): 2.6 ms per batch either way — 64 different paths in a wave wait for each other, and
+// one path per wave does every ordinary walk and every shading 64 times over: 9.7 -> 14.3 ms, suzanne at full size 71 -> 81-83 ms.)
+// Dynamic LDS: [TLAS stacks: tlas_levels x 64 u32][BLAS stacks: max(blas_levels x 64, EXACT_STACK) u32].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EXACT_WB) void k_exact_paths(DScene sc, DFrame f, float4 *__restrict__ sample_rad, uint32_t *__restrict__ totals, int use_bvh,
-                                                          uint32_t tlas_levels, uint32_t blas_levels, uint32_t fast_tlas_levels, uint32_t fast_levels) {
+__global__ __launch_bounds__(EXACT_WB) void k_extend_exact(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, int segment, int use_bvh, uint32_t tlas_levels) {
     extern __shared__ float4 lds_exact[];
-    __shared__ uint32_t seg_rays[MAX_SEGMENTS];       // this workgroup's rays per depth: one global atomic per workgroup and depth at the end
-                                                      // (one per RAY on eleven addresses was 2.3 of the kernel's 5 ms: ~88 atomics per us per address)
-    const uint32_t n = min(*f.ex.list_count, f.ex.list_cap);
+    const uint32_t n = min(f.ex.count[segment], f.ex.cap);
     if (n == 0u) return;
-    if (threadIdx.x < (uint32_t)MAX_SEGMENTS) seg_rays[threadIdx.x] = 0u;
-    if (sc.has_perlin) stage_perm();
-    const DScene &scl = sc;
-    float4 *p = lds_exact;
-    __syncthreads();
-    // ONE PATH PER WAVE (a workgroup is one wave): all 64 lanes carry the same path and execute the same instructions on the same
-    // values — the scalar part of a path costs what it cost one lane, no lane waits for another lane's different path (with 64
-    // paths per wave the wave's time was the SUM of its lanes' walks), a batch's few thousand paths fill the GPU's wave slots
-    // instead of a few dozen, and the literal mesh walk is shared by the lanes (hit_mesh_exact).  Stores of the same value to the
-    // same address by 64 lanes are one store; the counters below are lane 0's.
-    uint32_t *tlas_stack = reinterpret_cast<uint32_t *>(p) + threadIdx.x, *blas_stack = tlas_stack + (size_t)tlas_levels * EXACT_WB;   // blas: EXACT_STACK entries shared by the wave
-    // the stacks of the ordinary (culled) walk, [level][lane] like everywhere else: the segments of a listed path that
-    // are NOT flagged themselves take closest_hit — by the flag rule their result does not depend on the walk — so that a
-    // path costs one or two literal walks and not eleven
-    uint32_t *fast_stack = reinterpret_cast<uint32_t *>(p) + (size_t)(tlas_levels + blas_levels) * EXACT_WB + threadIdx.x;
-    uint32_t *fast_blas_stack = fast_stack + (size_t)fast_tlas_levels * 64u;
-    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
-        const float4 e0 = f.ex.list[3 * (size_t)k], e1 = f.ex.list[3 * (size_t)k + 1], e2 = f.ex.list[3 * (size_t)k + 2];
-        Ray r{mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y)};
-        V3 beta = mk(e1.z, e1.w, e2.x);
-        const uint32_t home = __float_as_uint(e2.y);
-        int seg = (int)__float_as_uint(e2.z);
-        const RngKey key = key_of(f, home);
-        [[maybe_unused]] const unsigned long long p0 = XP_NOW(); [[maybe_unused]] int nseg = 0;
-        for (bool first = true;; first = false) {
-            if (!first && threadIdx.x == 0) seg_rays[seg]++;           // the flagged segment itself sits in the wavefront's queue counts
-            float t = 2e9f; uint32_t obj = MISS, prim = 0;
-            [[maybe_unused]] const unsigned long long w0 = XP_NOW();
-            if (first || needs_exact(f.ex, r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z)) {
-                closest_hit_exact(scl, r, key, seg, use_bvh != 0, tlas_stack, blas_stack, t, obj, prim);
-                XP_ADD(2, 1); XP_ADD(3, XP_NOW() - w0);
-            } else {
-                bool deferred = false; uint32_t dobj = 0;
-                if (use_bvh) closest_hit<true, false>(sc, r, key, seg, fast_stack, fast_blas_stack, t, obj, prim, deferred, dobj);
-                else closest_hit<false, false>(sc, r, key, seg, fast_stack, fast_blas_stack, t, obj, prim, deferred, dobj);
-                XP_ADD(4, 1); XP_ADD(5, XP_NOW() - w0);
-            }
-            const uint32_t code = obj == MISS ? MISS : ((obj << sc.prim_bits) | prim);
-            Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0);
-            [[maybe_unused]] const unsigned long long s0 = XP_NOW();
-            const bool go_on = shade_path<false>(sc, f, sc.obj, sc.mat, sc.tex, r, beta, home, t, code, seg, sample_rad, nr, nbeta);
-            XP_ADD(6, XP_NOW() - s0); nseg++;
-            if (!go_on) break;
-            r = nr; beta = nbeta; seg++;
+    const uint32_t *__restrict__ list = f.ex.slots[segment & 1];
+    const uint32_t lane = threadIdx.x;                                  // a workgroup is one wave
+    uint32_t *tlas_stack = reinterpret_cast<uint32_t *>(lds_exact) + lane, *blas_stack = tlas_stack + (size_t)tlas_levels * EXACT_WB;
+    auto one = [&](uint32_t slot, auto form) {
+        const Ray r = make_ray(qld(&in.ray_a[slot]), load_ray_b(in, slot, f, segment), f, segment);
+        RngKey key{0, 0, 0};
+        if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, slot, segment).w));
+        float t = 2e9f; uint32_t obj = MISS, prim = 0;
+        closest_hit_exact<decltype(form)::value>(sc, r, key, segment, use_bvh != 0, tlas_stack, blas_stack, t, obj, prim);
+        const uint32_t code = obj == MISS ? MISS : ((obj << sc.prim_bits) | prim);
+        if (decltype(form)::value == 1 || lane == 0u) {
+            if (f.hit4) reinterpret_cast<uint32_t *>(hits)[slot] = code; else qst(&hits[slot], make_float2(t, __uint_as_float(code)));
         }
-#ifdef FW_EXACT_PROF
-        { const unsigned long long dt = XP_NOW() - p0; XP_ADD(0, 1); XP_ADD(1, nseg); XP_ADD(7, dt);
-          if (threadIdx.x == 0 && atomicMax(&g_xprof[8], dt) < dt) g_xprof[9] = (unsigned long long)nseg; }
-#endif
+    };
+    if (n <= EXACT_WAVE_RAYS * gridDim.x) {      // wave-uniform, the same for every wave of the launch
+        for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) one(list[k], std::integral_constant<int, 2>{});
+    } else {
+        for (uint32_t k = blockIdx.x * EXACT_WB + lane; k < n; k += gridDim.x * EXACT_WB) one(list[k], std::integral_constant<int, 1>{});
     }
-    if (blockIdx.x == 0) XP_ADD(10, 1);
-    __syncthreads();
-    if (threadIdx.x < (uint32_t)MAX_SEGMENTS && seg_rays[threadIdx.x]) atomicAdd(&totals[threadIdx.x], seg_rays[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2792,12 +2770,13 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)(DEFER0_CAP + DEFER1_CAP) * 12, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
-void launch_exact_paths(const LaunchCfg &c, const DScene &sc, const DFrame &f, float4 *sample_rad, uint32_t *totals, bool use_bvh) {
-    // stacks sized by the trees' depths: the reference trees for the literal walk, the walked trees for the ordinary one (launch_extend)
-    const uint32_t tl = std::min<uint32_t>(c.ref_tlas_depth + 2u, EXACT_LEVELS), bl = EXACT_STACK / EXACT_WB;
-    const uint32_t ftl = use_bvh ? (uint32_t)c.tlas_depth + 1u : 0u, fl = ftl + (uint32_t)c.blas_depth + 1u;
-    const size_t lds = (size_t)(tl + bl + fl) * EXACT_WB * 4;
-    hipLaunchKernelGGL(k_exact_paths, dim3((uint32_t)c.n_cus * 16u), dim3(EXACT_WB), lds, c.stream, sc, f, sample_rad, totals, use_bvh ? 1 : 0, tl, bl, ftl, fl);
+void launch_extend_exact(const LaunchCfg &c, const DScene &sc, const DFrame &f, const DPaths &in, float2 *hits, int segment, bool use_bvh) {
+    // stacks sized by the reference trees' depths; the wave-shared mesh stack needs EXACT_STACK entries whatever the depth
+    const uint32_t tl = std::min<uint32_t>(c.ref_tlas_depth + 2u, EXACT_LEVELS);
+    const uint32_t bl = std::max<uint32_t>(std::min<uint32_t>(c.ref_blas_depth + 2u, EXACT_LEVELS), EXACT_STACK / EXACT_WB);
+    const size_t lds = (size_t)(tl + bl) * EXACT_WB * 4;
+    // 8 single-wave workgroups per CU: most launches find an empty list, and dispatching 4 096 workgroups that only read a counter took 12 us
+    hipLaunchKernelGGL(k_extend_exact, dim3((uint32_t)c.n_cus * 8u), dim3(EXACT_WB), lds, c.stream, sc, f, in, hits, segment, use_bvh ? 1 : 0, tl);
 }
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment) {
@@ -2830,13 +2809,6 @@ void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else { if (lds_tab) FW_BOUNCE(false, true); else FW_BOUNCE(false, false); }
 #undef FW_BOUNCE
 }
-#ifdef FW_EXACT_PROF
-extern "C" int fw_debug_exact_prof(unsigned long long out[16]) {   // debug builds only; reads and clears the counters
-    unsigned long long zero[16] = {};
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_xprof), sizeof zero) != hipSuccess) return -1;
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_xprof), zero, sizeof zero) == hipSuccess ? 0 : -1;
-}
-#endif
 #ifdef FW_TRAV_STATS
 extern "C" int fw_debug_trav_stats(unsigned long long out[8]) {   // debug builds only; reads and clears the counters
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};

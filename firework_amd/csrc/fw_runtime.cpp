@@ -277,11 +277,10 @@ struct DevBuf {
 // depend on n (batches are accumulated in order).  Default 1: the measured gain is ~3 %.
 struct Workspace {
     static constexpr int MAX_LANES = 4;
-    // sample_rad / dep_bits / exact_bits / exact_list exist twice: with the exact walk on, a batch's tail (k_exact_paths, k_accumulate)
-    // runs on the tail stream while the lane's next batch is already traced into the other set
-    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad[2], wcount, park_a, park_b, park_m, pcount, dep_bits[2], exact_bits[2], exact_list[2];
-                  hipStream_t stream = nullptr; hipEvent_t ev_wave = nullptr, ev_free[2] = {nullptr, nullptr};
-                  std::vector<hipEvent_t> events, xevents; };
+    // exact_slots: the two slot lists of the exact walk (DExact.slots) + their counters behind them
+    struct Lane { DevBuf ray_a[2], ray_b[2], state[2], hits, sample_rad, wcount, park_a, park_b, park_m, pcount, dep_bits, exact_slots;
+                  hipStream_t stream = nullptr;
+                  std::vector<hipEvent_t> events; };
     std::mutex mu;                        // one fw_render at a time per device
     Lane lanes[MAX_LANES];
     DevBuf accum, totals, pixel_ids, out_rgb8, out_gamma, out_linear;
@@ -294,25 +293,19 @@ struct Workspace {
     hipEvent_t ev_upload = nullptr;       // after the latest scene upload on this device: renders wait for it in stream order
     hipStream_t upload_stream = nullptr;  // the upload kernel's own non-blocking stream: a launch on the legacy NULL stream would
                                           // synchronise with every blocking stream of the process (torch's default stream included)
-    hipStream_t tail_stream = nullptr;    // the batches' tails (k_exact_paths, k_accumulate) of ALL lanes: one stream, because the runtime maps
-                                          // streams onto four hardware queues — the caller's, two lanes and one tail fill them; with a tail
-                                          // stream per lane a lane shared a queue with the other's 2.5 ms exact kernel (suzanne 80 -> 99 ms)
     void release() {
         if (ev_d2h) { (void)hipEventDestroy(ev_d2h); ev_d2h = nullptr; }
         if (ev_upload) { (void)hipEventSynchronize(ev_upload); (void)hipEventDestroy(ev_upload); ev_upload = nullptr; }
         if (upload_stream) { (void)hipStreamDestroy(upload_stream); upload_stream = nullptr; }
-        if (tail_stream) { (void)hipStreamDestroy(tail_stream); tail_stream = nullptr; }
         if (staging) { (void)hipHostFree(staging); staging = nullptr; staging_bytes = 0; }
         if (host_out) { (void)hipHostFree(host_out); host_out = nullptr; host_out_bytes = 0; }
         tile_ids.release(); tile_w = tile_h = 0;
         for (DevBuf *b : {&accum, &totals, &pixel_ids, &out_rgb8, &out_gamma, &out_linear, &scene_cache}) b->release();
         for (Lane &l : lanes) {
-            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad[0], &l.sample_rad[1], &l.wcount, &l.park_a, &l.park_b,
-                              &l.park_m, &l.pcount, &l.dep_bits[0], &l.dep_bits[1], &l.exact_bits[0], &l.exact_bits[1], &l.exact_list[0], &l.exact_list[1]}) b->release();
+            for (DevBuf *b : {&l.ray_a[0], &l.ray_a[1], &l.ray_b[0], &l.ray_b[1], &l.state[0], &l.state[1], &l.hits, &l.sample_rad, &l.wcount, &l.park_a, &l.park_b,
+                              &l.park_m, &l.pcount, &l.dep_bits, &l.exact_slots}) b->release();
             for (hipEvent_t e : l.events) (void)hipEventDestroy(e);
-            for (hipEvent_t e : l.xevents) (void)hipEventDestroy(e);
-            l.events.clear(); l.xevents.clear();
-            for (hipEvent_t *e : {&l.ev_wave, &l.ev_free[0], &l.ev_free[1]}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+            l.events.clear();
             if (l.stream) (void)hipStreamDestroy(l.stream);
             l.stream = nullptr;
         }
@@ -581,7 +574,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     try { bvh_build(tlas, world); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
     std::vector<uint32_t> obj_rank = reference_ranks(tlas, desc->n_objects);
     uint32_t ref_tlas_nodes = tlas.count();
-    const std::vector<float> ref_tlas = tlas.nodes;          // the reference's own tree: what k_exact_paths walks
+    const std::vector<float> ref_tlas = tlas.nodes;          // the reference's own tree: what k_extend_exact walks
     const uint32_t ref_tlas_depth = tlas.depth;
     {   // the exact walk's flag rule (fw_device.h DExact)
         if (!fl.tri.empty()) ex.mode |= 1u;
@@ -930,32 +923,15 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     const uint32_t exact_mode = fused_req ? 0u : ((sc->ex.mode & 1u) | (p->use_bvh ? (sc->ex.mode & 6u) : ((sc->ex.mode & 4u) && sc->d.has_mesh ? 4u : 0u)));
     const bool tlas_refill = [] { const char *tr = getenv("FIREWORK_TLAS_REFILL"); return !(tr && atoi(tr) == 0); }();
     const bool park_meshes = p->use_bvh && sc->d.has_mesh != 0 && tlas_refill;
-    // The tail of a batch — the paths that left the wavefront (k_exact_paths: as long as its longest path, ~2.5 ms on suzanne) and
-    // k_accumulate — runs on the workspace's tail stream while the lane's next batch is traced into a second set of radiance /
-    // flag buffers: the latency is paid once per frame instead of once per batch.  Only where a lane has a next batch.
-    // Only with ONE lane: with two, the other lane's batch already fills the gap, and a third busy stream cost more than it hid
-    // (suzanne, two lanes: 80.6 ms without the tail stream, 86.2 with one, 99 with one per lane — streams share four hardware
-    // queues; one lane: 88.6 without, 82.3 with).  FIREWORK_TAIL_STREAM=0/1 overrides.
-    const char *tail_env = getenv("FIREWORK_TAIL_STREAM");
-    const bool tail_streams = exact_mode != 0 && n_batches > (uint32_t)n_lanes && (tail_env ? atoi(tail_env) != 0 : n_lanes == 1);
     int rc = FW_OK;
     auto need = [&](DevBuf &b, size_t n) { if (!rc) rc = b.alloc(n); };
     for (int l = 0; l < n_lanes; l++) {
         Workspace::Lane &L = ws->lanes[l];
         for (int k = 0; k < 2; k++) { need(L.ray_a[k], (size_t)cap * 16); need(L.ray_b[k], (size_t)cap * 8); need(L.state[k], (size_t)cap * 16); }
         need(L.hits, (size_t)cap * 8);
-        for (int k = 0; k < (tail_streams ? 2 : 1); k++) {
-            need(L.sample_rad[k], (size_t)cap * 16);              // indexed by home slot
-            need(L.dep_bits[k], ((size_t)cap + 31) / 32 * 4);     // one bit per slot: "a radiance record was written here" (black environments)
-        }
-        if (exact_mode) for (int k = 0; k < (tail_streams ? 2 : 1); k++) {
-            need(L.exact_bits[k], ((size_t)cap + 63) / 64 * 8 + 64);     // one bit per slot: "this path has left the wavefront", + the list's counter
-            need(L.exact_list[k], (size_t)max_paths * 48);               // the paths that left (ray + throughput + home slot + segment): at most every path of the batch
-        }
-        if (!rc && tail_streams) {
-            if (!ws->tail_stream) HIPCHK(hipStreamCreateWithFlags(&ws->tail_stream, hipStreamNonBlocking));
-            for (hipEvent_t *e : {&L.ev_wave, &L.ev_free[0], &L.ev_free[1]}) if (!*e) HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        }
+        need(L.sample_rad, (size_t)cap * 16);              // indexed by home slot
+        need(L.dep_bits, ((size_t)cap + 31) / 32 * 4);     // one bit per slot: "a radiance record was written here" (black environments)
+        if (exact_mode) need(L.exact_slots, 2 * (size_t)max_paths * 4 + 64);   // two lists of at most every ray of a segment, + the counters
         need(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
         if (park_meshes) {     // rays handed from k_extend_tlas_park to k_blas: 40 B per slot
             const size_t pcap = (size_t)(q.cap + 64u) * q.n_waves;     // park regions: q.cap + 64 entries per queue (DPark.stride)
@@ -1027,17 +1003,16 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     const fw::DEnv &env = sc->d.env;
     // (pixel-major bits need the sample index of a path from a float quotient that is exact only while spp_batch < 2^21: dep_bit_of)
     fr.dep_pixel_major = (((n_pix <= 65536u && getenv("FIREWORK_DEP_SLOT_MAJOR") == nullptr) || getenv("FIREWORK_DEP_PIXEL_MAJOR") != nullptr) && spp_b < (1u << 21)) ? 1u : 0u;
-    fr.ex = sc->ex; fr.ex.mode = exact_mode; fr.ex.bits = nullptr;
+    fr.ex = sc->ex; fr.ex.mode = exact_mode;
     fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && getenv("FIREWORK_NO_ZERO_SKIP") == nullptr) ? 1u : 0u;
 
     // per-launch timing (FW_FLAG_TIME_KERNELS): one event after every launch on the launch's own stream; the end of
     // launch k is the start of launch k+1 of that lane.  With several lanes the intervals overlap in wall time.
     const bool timing = (p->flags & FW_FLAG_TIME_KERNELS) != 0;
     const bool count_deposits = (p->flags & FW_FLAG_COUNT_DEPOSITS) != 0 && fr.skip_zero_deposits != 0;   // otherwise every terminated path writes one
-    const size_t per_batch_launches = 1 + 2 * fw::MAX_SEGMENTS + 3;     // raygen, 11 x (extend, shade), exact paths, queue totals, accumulate
+    const size_t per_batch_launches = 1 + 3 * fw::MAX_SEGMENTS + 2;     // raygen, 11 x (extend, exact extend, shade), queue totals, accumulate
     std::vector<std::vector<int>> ev_class(n_lanes);   // per lane: class of the launch that ENDS at events[1 + k]
-    std::vector<size_t> ev_next(n_lanes, 0), xev_next(n_lanes, 0);
-    std::vector<std::vector<int>> xev_class(n_lanes);
+    std::vector<size_t> ev_next(n_lanes, 0);
     if (timing) for (int l = 0; l < n_lanes; l++) {
         size_t want = 1 + per_batch_launches * ((n_batches + n_lanes - 1) / n_lanes);
         auto &ev = ws->lanes[l].events;
@@ -1073,15 +1048,12 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         };
         if (timing && ev_next[l] == 0) (void)hipEventRecord(L.events[0], ls);
         fr.sample0 = first_sample + b * spp_b;
-        const int set = tail_streams ? (int)((b / (uint32_t)n_lanes) & 1u) : 0;     // which of the lane's two buffer sets this batch uses
-        if (tail_streams && b / (uint32_t)n_lanes >= 2u) HIPCHK(hipStreamWaitEvent(ls, L.ev_free[set], 0));   // its previous user has been accumulated
-        fr.dep_bits = (uint32_t *)L.dep_bits[set].p;
+        fr.dep_bits = (uint32_t *)L.dep_bits.p;
         if (fr.skip_zero_deposits) HIPCHK(hipMemsetAsync(fr.dep_bits, 0, ((size_t)cap + 31) / 32 * 4, ls));
         if (exact_mode) {
-            fr.ex.bits = (uint32_t *)L.exact_bits[set].p;
-            fr.ex.list_count = fr.ex.bits + ((size_t)cap + 63) / 64 * 2;       // behind the bitmap
-            fr.ex.list = (float4 *)L.exact_list[set].p; fr.ex.list_cap = max_paths;
-            HIPCHK(hipMemsetAsync(fr.ex.bits, 0, ((size_t)cap + 63) / 64 * 8 + 64, ls));
+            fr.ex.slots[0] = (uint32_t *)L.exact_slots.p; fr.ex.slots[1] = fr.ex.slots[0] + max_paths;
+            fr.ex.count = fr.ex.slots[1] + max_paths; fr.ex.cap = max_paths;
+            HIPCHK(hipMemsetAsync(fr.ex.count, 0, 64, ls));
         }
         fr.spp_batch = std::min(spp_b, p->samples - b * spp_b);
         uint32_t n_paths = n_pix * fr.spp_batch;
@@ -1089,7 +1061,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         fw::DPaths buf[2];
         for (int k = 0; k < 2; k++) buf[k] = {(float4 *)L.ray_a[k].p, (float2 *)L.ray_b[k].p, (float4 *)L.state[k].p};
         float2 *hits = (float2 *)L.hits.p;
-        float4 *srad = (float4 *)L.sample_rad[set].p, *accum = (float4 *)ws->accum.p;
+        float4 *srad = (float4 *)L.sample_rad.p, *accum = (float4 *)ws->accum.p;
         const fw::DPark park{(float4 *)L.park_a.p, (float2 *)L.park_b.p, (float4 *)L.park_m.p, q.cap + 64u, (uint32_t *)L.pcount.p,
                              park_meshes ? (uint32_t *)L.pcount.p + q.n_waves : nullptr};
         if (park_meshes) HIPCHK(hipMemsetAsync(park.ptotal, 0, (size_t)q.n_waves * 4, ls));
@@ -1099,6 +1071,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
             else {
                 timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park); });
+                // the rays whose result depends on how the trees are walked (DExact), walked the reference's way: their hit records replaced
+                if (exact_mode) timed(1, [&] { fw::launch_extend_exact(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh); });
                 if (dump_one) {     // debug (tools/diverge.py): the one path of this call sits in slot 0 of wave 0 in every segment
                     float *r = &dump_rec[(size_t)seg * 16];
                     uint32_t alive = 0;
@@ -1115,39 +1089,14 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             cur ^= 1;
         }
         timed(3, [&] { fw::launch_queue_totals(cfg, totals, park.ptotal); });       // reads this batch's queue counts: before the lane's next batch overwrites them
-        // the tail: the paths that left the wavefront (DExact) are finished, once per batch, with the reference's own walk; then the sums
-        hipStream_t ts = ls;
-        auto xtimed = [&](int cls, auto &&launch) {      // like timed(), for launches on the tail stream: their own event pairs
-            if (!tail_streams) { timed(cls, launch); return; }
-            if (timing) {
-                while (L.xevents.size() < xev_next[l] + 2) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; L.xevents.push_back(e); }
-                (void)hipEventRecord(L.xevents[xev_next[l]], ts);
-            }
-            launch();
-            if (timing) { (void)hipEventRecord(L.xevents[xev_next[l] + 1], ts); xev_next[l] += 2; xev_class[l].push_back(cls); }
-        };
-        if (tail_streams) {
-            HIPCHK(hipEventRecord(L.ev_wave, ls));
-            ts = ws->tail_stream;
-            HIPCHK(hipStreamWaitEvent(ts, L.ev_wave, 0));
-            cfg.stream = ts;
-        }
-        if (exact_mode) xtimed(1, [&] { fw::launch_exact_paths(cfg, sc->d, fr, srad, totals, use_bvh); });
-        if (exact_mode && getenv("FIREWORK_TRACE")) {          // how many paths took the exact walk (debug: synchronises)
-            uint32_t c = 0;
-            HIPCHK(hipMemcpyAsync(&c, fr.ex.list_count, 4, hipMemcpyDeviceToHost, ts));
-            HIPCHK(hipStreamSynchronize(ts));
-            fprintf(stderr, "[firework] batch %u: %u of %u paths left the wavefront for the exact walk\n", b, c, n_paths);
-        }
         if (count_deposits) fw::launch_count_deposits(cfg, fr.dep_bits, totals + 12);   // not a kernel class: after the last timed event of its neighbours
         // `total_color += color(..)` in sample order (render.rs:181): batch b is accumulated after batch b-1, whichever
         // lanes they ran on, so the image does not depend on the number of lanes or batches
-        if ((n_lanes > 1 || tail_streams) && b > 0) HIPCHK(hipStreamWaitEvent(ts, ws->events[3 + b - 1], 0));
-        xtimed(3, [&] { fw::launch_accumulate(cfg, fr, srad, accum); });
-        if (n_lanes > 1 || tail_streams) HIPCHK(hipEventRecord(ws->events[3 + b], ts));
-        if (tail_streams) { HIPCHK(hipEventRecord(L.ev_free[set], ts)); cfg.stream = ls; }
+        if (n_lanes > 1 && b > 0) HIPCHK(hipStreamWaitEvent(ls, ws->events[3 + b - 1], 0));
+        timed(3, [&] { fw::launch_accumulate(cfg, fr, srad, accum); });
+        if (n_lanes > 1) HIPCHK(hipEventRecord(ws->events[3 + b], ls));
     }
-    if (n_lanes > 1 || tail_streams) HIPCHK(hipStreamWaitEvent(stream, ws->events[3 + n_batches - 1], 0));    // join
+    if (n_lanes > 1) HIPCHK(hipStreamWaitEvent(stream, ws->events[3 + n_batches - 1], 0));    // join
     cfg.stream = stream;
     fw::launch_resolve(cfg, fr, (const float4 *)ws->accum.p, first_sample + p->samples, p->gamma, d_rgb8, d_gamma, d_linear);
     if (user_accum) HIPCHK(hipMemcpyAsync(user_accum, ws->accum.p, (size_t)n_pix * 16, p->outputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
@@ -1241,12 +1190,6 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
                     float t = 0.f;
                     HIPCHK(hipEventElapsedTime(&t, ws->lanes[l].events[i], ws->lanes[l].events[i + 1]));
                     acc[ev_class[l][i]] += t;
-                }
-            for (int l = 0; l < n_lanes; l++)
-                for (size_t i = 0; i < xev_class[l].size(); i++) {
-                    float t = 0.f;
-                    HIPCHK(hipEventElapsedTime(&t, ws->lanes[l].xevents[2 * i], ws->lanes[l].xevents[2 * i + 1]));
-                    acc[xev_class[l][i]] += t;
                 }
             stats->ms_raygen = acc[0]; stats->ms_extend = acc[1]; stats->ms_shade = acc[2]; stats->ms_accumulate = acc[3];
         }
