@@ -690,6 +690,15 @@ __device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, 
     if (!hl && !hr) { next = REF_DONE; if (st.sp) next = st.pop(); }
     return next;
 }
+// (Round 3, measured and removed — tools/experiments/r03_lds_planes.diff: for the LDS-resident walks the nodes as seven PLANES of
+// float2 (left, right) per number, each lane reading the near and far planes its ray's signs select (no selects: 27 vector
+// instructions for the two box tests instead of 56, the subtractions and multiplications as v_pk_add_f32 / v_pk_mul_f32) and
+// ds_read_b64 at 8-byte stride instead of whole nodes 64 bytes apart (whose quads fall on 4 of 16 slots of a bank row: 4-way
+// conflicts in every lane group, ~96 LDS cycles per step).  Bit-identical, GPU suite green — and k_blas_lds 448 -> 430 us per
+// launch, suzanne 65.4 -> 65.6 ms, part2 @16 10.6 -> 10.7: nothing.  The packed instructions take two passes each (the same
+// cycles as the scalar pairs), and the step is not bound by its box arithmetic or by LDS cycles but by the serial issue of one
+// wave's ~110 instructions with 2.4 waves per SIMD to hide it.  The same planes read as single dwords from whole nodes
+// (ds_read2_b32, 16-dword stride: 16-way conflicts) cost +20 %: suzanne 65 -> 78 ms.)
 // best t -> culling bound, a little beyond it whatever its sign (a medium's inner mesh is walked with t in (-MAX, MAX))
 #ifdef FW_NO_CULL     // A/B build (tools/diverge.py): no culling against the best hit, every box test is the reference's alone
 __device__ __forceinline__ float cull_bound(float) { return 3.40282347e+38f; }
