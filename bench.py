@@ -151,6 +151,7 @@ def main():
     for _ in range(args.warmup):
         tr.render_frame()
     barrier()
+    tr.take_gather_ms()
     t0 = time.perf_counter()
     keys = ("rays", "samples", "ms_render", "ms_extend", "ms_shade", "ms_raygen", "ms_accumulate", "n_extend_launches",
             "n_shade_launches", "bytes_raygen", "bytes_extend", "bytes_shade", "bytes_accumulate", "algorithmic_bytes")
@@ -160,9 +161,9 @@ def main():
         tr.render_frame()
         for k in acc:
             acc[k] += tr.last_stats[k]
-        ms_gather += tr.last_ms_gather
-    barrier()
+    barrier()                     # device-wide: the last frame's gather (its own stream when there is a collective) included
     elapsed = time.perf_counter() - t0
+    ms_gather = tr.take_gather_ms()
 
     # max over ranks of the elapsed time; sums over ranks of the work counters
     vec = torch.tensor([elapsed, acc["rays"], acc["samples"], acc["ms_extend"], acc["ms_shade"], acc["ms_render"], ms_gather],

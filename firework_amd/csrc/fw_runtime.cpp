@@ -884,6 +884,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // Round 3: a linear scene whose scan runs the box lists (k_extend_linear_defer: cornell) takes two lanes as well — its scan is
     // bound by instruction issue, its k_shade by HBM, and they overlap (42.2 -> 40.3 ms in round 2's A/B); per-kernel times for
     // the roofline come from an exclusive pass (FIREWORK_STREAMS=1) that bench.py runs next to the timed loop.
+    // (Small frames too: random_spheres, 5.8 M paths, 1.83 ms in two batches against 1.92-1.97 in one, round 3.)
     int n_lanes = (p->use_bvh || sc->n_defer > 0) ? 2 : 1;
     if (const char *e = getenv("FIREWORK_STREAMS")) { int v = atoi(e); if (v >= 1) n_lanes = std::min(v, (int)Workspace::MAX_LANES); }
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, p->samples);

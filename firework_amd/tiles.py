@@ -56,7 +56,9 @@ class TileGather:
         self.ids = np.ascontiguousarray(all_ids[rank])
         self.counts = [int(a.shape[0]) for a in all_ids]
         self.n_local, self.n_max = self.counts[rank], max(self.counts)
-        self.local = torch.zeros((self.n_max, 3), dtype=torch.uint8, device=device)   # padded to equal size for gather
+        # padded to equal size for gather; two of them, so that frame k's tiles can be gathered while frame k+1 is rendered (TiledRenderer)
+        self.locals = [torch.zeros((self.n_max, 3), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.local = self.locals[0]
         self.frame = None
         if rank == 0:
             self.frame = torch.zeros((width * height, 3), dtype=torch.uint8, device=device)
@@ -64,20 +66,21 @@ class TileGather:
             if self.collective:
                 self.gather_list = [torch.zeros((self.n_max, 3), dtype=torch.uint8, device=device) for _ in range(world)]
 
-    def assemble(self):
-        """`self.local[:n_local]` holds this rank's finished pixels -> full frame on rank 0 (None elsewhere)."""
+    def assemble(self, local=None):
+        """`local[:n_local]` (default `self.local`) holds this rank's finished pixels -> full frame on rank 0 (None elsewhere)."""
+        local = self.local if local is None else local
         if not self.collective:
-            self.frame.index_copy_(0, self.all_ids_dev[0], self.local[: self.n_local])
+            self.frame.index_copy_(0, self.all_ids_dev[0], local[: self.n_local])
             return self.frame
         # the only collective of the whole path: <= W*H*3 bytes in total
         if self.host_staged:     # rehearsal mode (gloo): same call, tensors staged through host memory
             got = [self.torch.empty((self.n_max, 3), dtype=self.torch.uint8) for _ in range(self.world)] if self.rank == 0 else None
-            self.dist.gather(self.local.cpu(), got, dst=0)
+            self.dist.gather(local.cpu(), got, dst=0)
             if self.rank == 0:
                 for r in range(self.world):
                     self.gather_list[r].copy_(got[r])
         else:
-            self.dist.gather(self.local, self.gather_list if self.rank == 0 else None, dst=0)
+            self.dist.gather(local, self.gather_list if self.rank == 0 else None, dst=0)
         if self.rank != 0:
             return None
         for r in range(self.world):
@@ -99,25 +102,66 @@ class TiledRenderer:
         torch.cuda.set_device(self.dev)
         self.tg = TileGather(s["width"], s["height"], rank, world, self.dev, dist, tile, host_staged=host_staged_gather,
                              force_collective=force_collective)
-        self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         self.last_ms_gather = 0.0
         self.scene = _lib.DeviceScene(scene if hasattr(scene, "ptr") else scene.to_desc(), device)
         self.world = world
         self.last_stats = None
         self.frame = None
+        # With a collective, the gather (and rank 0's scatter of the shares into the frame) of frame k runs on its own stream
+        # while frame k+1 is rendered into the other tile buffer: at 8 ranks a cornell frame is ~5 ms per rank, and rank 0's
+        # serial gather + eight scatters would otherwise sit between every two frames.  The frames are the same either way.
+        self.side = torch.cuda.Stream(self.dev) if self.tg.collective and not host_staged_gather else None
+        self.n_frames = 0
+        self.gather_done = [None, None]       # per tile buffer: the event after its last gather
+        self.gather_events = []               # (start, stop) pairs of the gathers not yet summed by take_gather_ms()
 
     def render_frame(self):
-        """Returns the (H*W,3) uint8 device tensor on rank 0 (None elsewhere)."""
-        stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+        """Returns the (H*W,3) uint8 device tensor on rank 0 (None elsewhere).  With a collective the tensor is complete once
+        `wait()` (or any device-wide synchronisation) has returned: the gather of this frame overlaps the next render."""
+        torch = self.torch
+        main = torch.cuda.current_stream(self.dev)
+        k = self.n_frames & 1
+        local = self.tg.locals[k] if self.side is not None else self.tg.local
+        self.n_frames += 1
+        if self.side is not None and self.gather_done[k] is not None:
+            main.wait_event(self.gather_done[k])            # the buffer's previous tiles have been sent
         self.last_stats = self.scene.render(self.renderer, pixel_ids=self.tg.ids,
-                                            out_device_ptrs=(self.tg.local.data_ptr(), None, None), stream=stream)
-        # the gather (and the scatter of the tiles into the frame) on torch's current stream = the stream fw_render ran on
-        self.ev[0].record()
-        self.frame = self.tg.assemble()
-        self.ev[1].record()
-        self.ev[1].synchronize()
-        self.last_ms_gather = self.ev[0].elapsed_time(self.ev[1])
+                                            out_device_ptrs=(local.data_ptr(), None, None), stream=main.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if self.side is None:
+            # the gather (and the scatter of the tiles into the frame) on torch's current stream = the stream fw_render ran on
+            e0.record()
+            self.frame = self.tg.assemble(local)
+            e1.record()
+            e1.synchronize()
+            self.last_ms_gather = e0.elapsed_time(e1)
+            self.gather_events.append((e0, e1))
+            return self.frame
+        rendered = torch.cuda.Event()
+        rendered.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(rendered)
+            e0.record()
+            self.frame = self.tg.assemble(local)
+            e1.record()
+        self.gather_done[k] = e1
+        self.gather_events.append((e0, e1))
         return self.frame
+
+    def wait(self):
+        """Until every gather issued so far has finished (the frame returned by the last render_frame() is complete)."""
+        if self.side is not None:
+            self.side.synchronize()
+
+    def take_gather_ms(self):
+        """Device time of the gathers since the last call, in ms (waits for them)."""
+        self.wait()
+        ms = 0.0
+        for e0, e1 in self.gather_events:
+            e1.synchronize()
+            ms += e0.elapsed_time(e1)
+        self.gather_events = []
+        return ms
 
     def close(self):
         self.scene.close()

@@ -7,7 +7,7 @@ same length, same colour — and the frames they come from must have equal ray c
                                                   median form of the rectangle test rejected them (hit_rect: literal t interval now)
   C3 suzanne 1280x720, five pixels                rays whose SIGNED largest direction component is tiny (util.rs:104-118 picks it as
                                                   the shear axis of mesh.rs:147-162): shear factors of 10^4, "hits" outside the
-                                                  triangle's box, found or not depending on the walk (k_exact_paths walks them)
+                                                  triangle's box, found or not depending on the walk (k_extend_exact walks them)
   C5 part2 1920x1080, two pixels                  rays from ~1000 units away in the fog against spheres of radius 0.1: the discriminant is
                                                   rounding noise and the reference tests the sphere behind its DoubleLeaf's box (k_exact_paths)
   (the other eight C5 paths of that hunt started with the fog medium's log10f, ocml vs glibc by one ulp: fw_libm.h)"""
@@ -56,7 +56,7 @@ def test_ray_counts_per_depth_equal_the_oracles_on_the_frames_they_came_from(ora
 
 
 def test_every_ray_through_the_exact_walk_gives_the_same_frames(oracle, monkeypatch):
-    """FIREWORK_EXACT_ALL=1: every ray is traced by the literal reference walk (k_exact_paths) — the renderer then IS bvh.rs:115-151 —
+    """FIREWORK_EXACT_ALL=1: every ray is traced by the literal reference walk (k_extend_exact) — the renderer then IS bvh.rs:115-151 —
     and the frame equals the default one (fast walks + the flagged few) and the oracle's."""
     for name, w, h, spp in (("C3_suzanne", 320, 180, 8), ("C5_part2_all", 240, 135, 4), ("C1_random_spheres", 200, 112, 8)):
         scene, renderer = scenes.config(name, w, h, spp)

@@ -23,7 +23,7 @@ def full_check(oracle, scene, renderer, name):
     """GPU vs oracle, same seed: every path takes the same segments (ray counts per depth equal), every u8 of the image is
     equal, and the float means agree to the rounding of a different product order (beta is multiplied left to right on the
     device, right to left by the reference's recursion).  No pixel is tolerated: the libm-class functions are glibc's
-    (fw_libm.h) and the rays whose result depends on traversal order take the reference's own walk (k_exact_paths)."""
+    (fw_libm.h) and the rays whose result depends on traversal order take the reference's own walk (k_extend_exact)."""
     gpu = renderer.render_full(scene)
     cpu = oracle.render(scene, renderer)
     g, c = np.nan_to_num(gpu.gamma.astype(np.float64)), np.nan_to_num(cpu.gamma.astype(np.float64))
