@@ -298,6 +298,11 @@ def device_info(device_index):
             d = json.loads(cp.stdout)
             card = d.get(f"card{device_index}") or next(iter(d.values()))
             info["rocm_smi_clocks"] = {k: v for k, v in card.items() if "clk" in k.lower()}
+            import re
+            for name in ("sclk", "mclk"):       # "(2362Mhz)": what the card runs at now; torch's properties report 0 on this image
+                m = re.search(r"(\d+)\s*mhz", str(card.get(f"{name} clock speed:", "")), re.I)
+                if m and not info.get(f"{name}_mhz"):
+                    info[f"{name}_mhz"] = float(m.group(1))
     except Exception:
         pass
     return info
