@@ -122,7 +122,10 @@ __device__ __forceinline__ uint4 draw(const RngKey &k, uint32_t purpose, uint32_
     return pcg4d(make_uint4(k.pixel, k.sample, purpose | (segment << 3) | (index << 7), k.seed32));
 }
 
-constexpr uint32_t MAX_REJECT = 1024;   // exit condition for the rejection loops (P(miss 1024x) ~ 1e-330)
+#ifndef FW_MAX_REJECT
+#define FW_MAX_REJECT 1024
+#endif
+constexpr uint32_t MAX_REJECT = FW_MAX_REJECT;   // exit condition for the rejection loops (P(miss 1024x) ~ 1e-330)
 
 // util.rs:36-43
 __device__ __forceinline__ V3 random_in_unit_sphere(const RngKey &k, uint32_t segment) {
@@ -690,6 +693,10 @@ __device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, 
     if (!hl && !hr) { next = REF_DONE; if (st.sp) next = st.pop(); }
     return next;
 }
+// (Round 3, also measured and removed — tools/experiments/r03_branchfree_stack.diff: the step without its three predicated regions
+// (the stack's top read with the node, the farther child written to the free slot whether or not it is kept, the count moved by
+// a select): k_blas_lds 448 -> 422 us per launch, and the frames within the boxes' noise or worse — suzanne 65.4 -> 66.2 ms, @64
+// 10.1 -> 10.5, part2 @16 10.7 -> 11.0, teapot @32 15.5 -> 15.7.)
 // (Round 3, measured and removed — tools/experiments/r03_lds_planes.diff: for the LDS-resident walks the nodes as seven PLANES of
 // float2 (left, right) per number, each lane reading the near and far planes its ray's signs select (no selects: 27 vector
 // instructions for the two box tests instead of 56, the subtractions and multiplications as v_pk_add_f32 / v_pk_mul_f32) and
