@@ -925,11 +925,14 @@ struct Camera {
 // Debug probe (fwo_trace_path, tools/diverge.py): when set, color() records every segment of the path it follows —
 // 16 floats per depth: ray o, d | hit flag, t, material | point | normal | pad.
 thread_local float *g_path_trace = nullptr;
+// Debug probe (fwo_find_nan_paths): set when color() follows a ray whose six numbers do not sum to a number (a NaN, or +inf and -inf)
+thread_local bool g_nan_ray_seen = false;
 
 // render.rs:12-33
 V3 color(const Ray &r, const SceneInternal &scene, const Hitable &root, size_t depth, Rng &rng, uint64_t *rays_per_depth) {
     rng.segment = (uint32_t)depth;
     rays_per_depth[depth]++;
+    { const float sum = ((r.o.x + r.o.y) + r.o.z) + ((r.d.x + r.d.y) + r.d.z); if (sum != sum) g_nan_ray_seen = true; }
     Hit hit;
     const bool was_hit = root.hit(r, 0.001f, 2e9f, rng, hit);
     if (g_path_trace) {
@@ -1130,6 +1133,38 @@ int fwo_path_lengths(const fw_scene_desc *desc, const fw_render_params *params, 
         uint64_t len = 0; for (int d = 0; d < FW_MAX_SEGMENTS; d++) len += rpd[d];
         out[k] = (uint8_t)len;
     }
+    return FW_OK;
+}
+// The (pixel, sample) pairs of a CTR render whose path follows a ray with a NaN in it (the third class of DESIGN.md §6): out = pairs
+// of uint32, at most `cap` of them; *n_found = how many there are.
+int fwo_find_nan_paths(const fw_scene_desc *desc, const fw_render_params *params, int n_threads, uint32_t *out, uint32_t cap, uint32_t *n_found) {
+    if (!out || !n_found || !params || params->samples == 0) return FW_ERR_BAD_ARG;
+    ProbeCtx cx(desc, params);
+    if (cx.status) return cx.status;
+    Camera cam(params->camera, params->width, params->height);
+    const Hitable &root = cx.root(params);
+    size_t npix = params->pixel_ids ? params->n_pixels : (size_t)params->width * params->height;
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    std::atomic<size_t> next{0};
+    std::atomic<uint32_t> found{0};
+    auto worker = [&]() {
+        for (;;) {
+            size_t b = next.fetch_add(64);
+            if (b >= npix) break;
+            for (size_t i = b; i < std::min(npix, b + 64); i++) {
+                size_t idx = params->pixel_ids ? params->pixel_ids[i] : i;
+                for (uint32_t s = 0; s < params->samples; s++) {
+                    uint64_t rpd[FW_MAX_SEGMENTS + 1] = {0};
+                    g_nan_ray_seen = false;
+                    one_sample(*params, cx.scene, root, cam, idx, s, rpd);
+                    if (g_nan_ray_seen) { const uint32_t k = found.fetch_add(1); if (k < cap) { out[2 * k] = (uint32_t)idx; out[2 * k + 1] = s; } }
+                }
+            }
+        }
+    };
+    std::vector<std::thread> th; for (int t = 0; t < n_threads; t++) th.emplace_back(worker); for (auto &t : th) t.join();
+    *n_found = found.load();
     return FW_OK;
 }
 // Every segment of the path of (pixel, sample): out = 11 x 16 floats (see g_path_trace), colour = its radiance.

@@ -247,6 +247,18 @@ def render_counts(scene, renderer, pixel_ids=None, n_threads=0):
     return out
 
 
+def find_nan_paths(scene, renderer, pixel_ids=None, cap=4096, n_threads=0):
+    """(pixel, sample) pairs of a CTR render whose path follows a ray with a NaN in it, and how many there are in all."""
+    lib = load()
+    sd, _ids, p = _params(scene, renderer, pixel_ids)
+    out = np.zeros((cap, 2), np.uint32)
+    n = C.c_uint32(0)
+    rc = lib.fwo_find_nan_paths(sd.ptr(), C.byref(p), C.c_int(n_threads), out.ctypes.data_as(C.c_void_p), C.c_uint32(cap), C.byref(n))
+    if rc:
+        raise OracleError(rc)
+    return out[: min(cap, n.value)], n.value
+
+
 def path_lengths(scene, renderer, pixel, first_sample, n):
     """Segments (1..11) of the paths of samples first_sample .. first_sample+n-1 of one pixel."""
     lib = load()

@@ -9,8 +9,12 @@ same length, same colour — and the frames they come from must have equal ray c
                                                   the shear axis of mesh.rs:147-162): shear factors of 10^4, "hits" outside the
                                                   triangle's box, found or not depending on the walk (k_extend_exact walks them)
   C5 part2 1920x1080, two pixels                  rays from ~1000 units away in the fog against spheres of radius 0.1: the discriminant is
-                                                  rounding noise and the reference tests the sphere behind its DoubleLeaf's box (k_exact_paths)
-  (the other eight C5 paths of that hunt started with the fog medium's log10f, ocml vs glibc by one ulp: fw_libm.h)"""
+                                                  rounding noise and the reference tests the sphere behind its DoubleLeaf's box (k_extend_exact)
+  (the other eight C5 paths of that hunt started with the fog medium's log10f, ocml vs glibc by one ulp: fw_libm.h)
+  C3 suzanne 1280x720, pixel 415420, sample 43    found later by its COST (oracle.find_nan_paths): a bounce ray with d.z = 0 exactly whose
+                                                  other components are negative: util.rs:104-118 picks z, mesh.rs:160-162 divides by it,
+                                                  the triangle "hit" has t = NaN, the point is NaN and the path goes on for its remaining
+                                                  five segments with NaN rays that pass every box (k_extend_exact; the ordinary walks skip them)"""
 import copy
 
 import numpy as np
@@ -22,7 +26,7 @@ pytestmark = pytest.mark.gpu
 
 CASES = [
     ("C2_cornell_box", 512, 512, [(112819, 170)]),
-    ("C3_suzanne", 1280, 720, [(355384, 10), (360504, 9), (478225, 6), (525350, 14), (767410, 10)]),
+    ("C3_suzanne", 1280, 720, [(355384, 10), (360504, 9), (478225, 6), (525350, 14), (767410, 10), (415420, 43)]),
     ("C5_part2_all", 1920, 1080, [(148623, 0), (400990, 0), (139590, 3), (238497, 1), (442459, 3), (579166, 1), (628372, 0), (655626, 1), (900664, 1)]),
 ]
 

@@ -311,3 +311,19 @@ def test_bvh_and_linear_scene_agree_exactly_on_cornell(oracle):
     b = oracle.render(s, r.use_bvh(True))
     assert (np.abs(a.linear - b.linear).max(axis=1) > 0).sum() <= 2
     assert abs(a.stats["rays"] - b.stats["rays"]) <= 5
+
+
+def test_a_zero_shear_axis_gives_the_nan_hit_the_reference_gives(oracle):
+    """SURVEY §8(a), Triangle::hit: `max_component_idx` compares SIGNED values (util.rs:104-118), so a direction like
+    (-0.53, -0.38, 0.0) takes z as its shear axis, mesh.rs:160-162 divides by 0, every comparison of 177-194 is false for the NaNs
+    that follow, and a hit with t = NaN is returned: the point is NaN and the path goes on with NaN rays (every box passes,
+    every triangle "hits") until the depth limit ends it with nothing.  suzanne 1280x720, pixel 415420, sample 43 is such a path."""
+    scene, renderer = scenes.config("C3_suzanne", 1280, 720, 64)
+    pairs, n = oracle.find_nan_paths(scene, renderer, pixel_ids=np.array([415420], np.uint32))
+    assert n == 1 and pairs.tolist() == [[415420, 43]]
+    segs, colour = oracle.trace_path(scene.to_desc(), scenes.config("C3_suzanne", 1280, 720, 1)[1], 415420, 43)
+    assert int(segs[:, 15].sum()) == 11                                  # the full eleven segments
+    assert segs[6, 5] == 0.0 and segs[6, 3] < 0 and segs[6, 4] < 0         # the ray that does it: d.z = 0, the others negative
+    assert segs[6, 6] == 1.0 and np.isnan(segs[6, 7])                     # "hit", t = NaN
+    assert np.isnan(segs[7:, 0:6]).all() and (segs[7:, 6] == 1.0).all()   # NaN rays from then on, each of them a "hit"
+    assert colour.tolist() == [0.0, 0.0, 0.0]                             # depth 10 returns its emission: none
