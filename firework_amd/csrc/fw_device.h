@@ -196,6 +196,7 @@ struct LaunchCfg {
     uint32_t n_defer;     // linear scan: the scene's last n_defer (1 or 2) objects are plain Rect3d boxes handled by k_extend_linear_defer; 0: k_extend_linear
     bool lds_trees;       // walk trees that fit out of LDS (k_blas_lds); FIREWORK_NO_LDS_TREES=1 switches it off
     int shade_mode;       // k_shade: 0 everything in line, 1 the scene has no expensive material / environment (the cheap loop alone), 2 expensive paths go through a list (FIREWORK_SHADE_LIST=1: measured slower, kept for A/B)
+    int exact_form;               // k_extend_exact: 0 = by list length, 1 = one ray per lane, 2 = one ray per wave (FIREWORK_EXACT_FORM=lane|wave: tests)
     uint32_t ref_tlas_nodes, ref_blas_nodes, ref_tlas_depth, ref_blas_depth;   // the reference trees k_extend_exact walks (nodes of 32 B)
     bool tlas_refill;     // refilling walks: k_extend_tlas (no meshes) / k_extend_tlas_park + k_blas (meshes); FIREWORK_TLAS_REFILL=0: the chunked k_extend_bvh
 };

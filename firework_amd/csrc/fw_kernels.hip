@@ -2419,7 +2419,7 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
 // one path per wave does every ordinary walk and every shading 64 times over: 9.7 -> 14.3 ms, suzanne at full size 71 -> 81-83 ms.)
 // Dynamic LDS: [TLAS stacks: tlas_levels x 64 u32][BLAS stacks: max(blas_levels x 64, EXACT_STACK) u32].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(EXACT_WB) void k_extend_exact(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, int segment, int use_bvh, uint32_t tlas_levels) {
+__global__ __launch_bounds__(EXACT_WB) void k_extend_exact(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, int segment, int use_bvh, uint32_t tlas_levels, int form) {
     extern __shared__ float4 lds_exact[];
     const uint32_t n = min(f.ex.count[segment], f.ex.cap);
     if (n == 0u) return;
@@ -2437,7 +2437,7 @@ __global__ __launch_bounds__(EXACT_WB) void k_extend_exact(DScene sc, DFrame f, 
             if (f.hit4) reinterpret_cast<uint32_t *>(hits)[slot] = code; else qst(&hits[slot], make_float2(t, __uint_as_float(code)));
         }
     };
-    if (n <= EXACT_WAVE_RAYS * gridDim.x) {      // wave-uniform, the same for every wave of the launch
+    if (form == 2 || (form == 0 && n <= EXACT_WAVE_RAYS * gridDim.x)) {      // wave-uniform, the same for every wave of the launch (form: FIREWORK_EXACT_FORM, tests)
         for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) one(list[k], std::integral_constant<int, 2>{});
     } else {
         for (uint32_t k = blockIdx.x * EXACT_WB + lane; k < n; k += gridDim.x * EXACT_WB) one(list[k], std::integral_constant<int, 1>{});
@@ -2792,7 +2792,7 @@ void launch_extend_exact(const LaunchCfg &c, const DScene &sc, const DFrame &f, 
     const uint32_t bl = std::max<uint32_t>(std::min<uint32_t>(c.ref_blas_depth + 2u, EXACT_LEVELS), EXACT_STACK / EXACT_WB);
     const size_t lds = (size_t)(tl + bl) * EXACT_WB * 4;
     // 8 single-wave workgroups per CU: most launches find an empty list, and dispatching 4 096 workgroups that only read a counter took 12 us
-    hipLaunchKernelGGL(k_extend_exact, dim3((uint32_t)c.n_cus * 8u), dim3(EXACT_WB), lds, c.stream, sc, f, in, hits, segment, use_bvh ? 1 : 0, tl);
+    hipLaunchKernelGGL(k_extend_exact, dim3((uint32_t)c.n_cus * 8u), dim3(EXACT_WB), lds, c.stream, sc, f, in, hits, segment, use_bvh ? 1 : 0, tl, c.exact_form);
 }
 void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, const float2 *hits,
                   float4 *sample_rad, int segment) {

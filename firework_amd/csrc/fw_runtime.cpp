@@ -982,6 +982,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.no_lds_tris = getenv("FIREWORK_NO_LDS_TRIS") != nullptr;
     cfg.n_defer = (!p->use_bvh && getenv("FIREWORK_NO_DEFER") == nullptr) ? sc->n_defer : 0u;
     cfg.lds_trees = getenv("FIREWORK_NO_LDS_TREES") == nullptr;
+    { const char *ef = getenv("FIREWORK_EXACT_FORM"); cfg.exact_form = ef ? (strcmp(ef, "lane") == 0 ? 1 : (strcmp(ef, "wave") == 0 ? 2 : 0)) : 0; }
     cfg.ref_tlas_nodes = sc->tlas_nodes; cfg.ref_blas_nodes = sc->blas_nodes; cfg.ref_tlas_depth = sc->ref_tlas_depth; cfg.ref_blas_depth = sc->ref_blas_depth;
     // k_shade's list entries are 16-bit queue positions: longer queues (cap > 65536: never with the default geometry) shade in line
     // Default: the cheap loop alone where the scene has nothing expensive (cornell k_shade -5 %), everything in line otherwise — the

@@ -61,14 +61,19 @@ def test_ray_counts_per_depth_equal_the_oracles_on_the_frames_they_came_from(ora
 
 def test_every_ray_through_the_exact_walk_gives_the_same_frames(oracle, monkeypatch):
     """FIREWORK_EXACT_ALL=1: every ray is traced by the literal reference walk (k_extend_exact) — the renderer then IS bvh.rs:115-151 —
-    and the frame equals the default one (fast walks + the flagged few) and the oracle's."""
-    for name, w, h, spp in (("C3_suzanne", 320, 180, 8), ("C5_part2_all", 240, 135, 4), ("C1_random_spheres", 200, 112, 8)):
+    and the frame equals the default one (fast walks + the flagged few) and the oracle's.  In both forms of the walk: one ray per
+    lane (what a list of that length takes by itself) and one ray per wave with the shared walk (FIREWORK_EXACT_FORM=wave)."""
+    for name, w, h, spp in (("C3_suzanne", 320, 180, 8), ("C5_part2_all", 240, 135, 4), ("C1_random_spheres", 200, 112, 8), ("teapot", 160, 90, 4)):
         scene, renderer = scenes.config(name, w, h, spp)
         monkeypatch.delenv("FIREWORK_EXACT_ALL", raising=False)
+        monkeypatch.delenv("FIREWORK_EXACT_FORM", raising=False)
         fast = renderer.render_full(scene)
-        monkeypatch.setenv("FIREWORK_EXACT_ALL", "1")
-        exact = renderer.render_full(scene)
-        monkeypatch.delenv("FIREWORK_EXACT_ALL", raising=False)
         cpu = oracle.render(scene, renderer)
-        assert exact.stats["rays_per_depth"] == cpu.stats["rays_per_depth"] == fast.stats["rays_per_depth"], name
-        assert np.array_equal(exact.linear, fast.linear) and np.array_equal(exact.rgb8, cpu.rgb8), name
+        monkeypatch.setenv("FIREWORK_EXACT_ALL", "1")
+        for form in ("lane", "wave"):
+            monkeypatch.setenv("FIREWORK_EXACT_FORM", form)
+            exact = renderer.render_full(scene)
+            assert exact.stats["rays_per_depth"] == cpu.stats["rays_per_depth"] == fast.stats["rays_per_depth"], (name, form)
+            assert np.array_equal(exact.linear, fast.linear, equal_nan=True) and np.array_equal(exact.rgb8, cpu.rgb8), (name, form)
+        monkeypatch.delenv("FIREWORK_EXACT_ALL", raising=False)
+        monkeypatch.delenv("FIREWORK_EXACT_FORM", raising=False)
