@@ -1919,6 +1919,98 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
 // (DExact, fw_device.h).  Nodes from L2, stacks in LDS.  With FIREWORK_EXACT_ALL=1 every ray takes it: the renderer then IS the
 // reference's traversal.
 // ------------------------------------------------------------------------------------------------
+// The literal TLAS walk, one ray per wave (the wave form of k_extend_exact under use_bvh): hit_mesh_exact_wave's scheme one level up.
+// The lanes pop up to 64 nodes of a shared stack per round; a lane that pops a leaf tests its objects itself — except objects with a
+// mesh inside, whose own walk wants the whole wave: those go on a short list and are walked afterwards, one after the other, by
+// all lanes together.  Winner: smallest t, the later item in depth-first order on a tie; a NaN t the way the reference's rule
+// treats it (see hit_mesh_exact_wave: second pass behind the last NaN hit).  Returns false, having decided nothing, when more
+// than EXACT_DEFER mesh objects are reached (the caller then walks node by node).
+// ws: EXACT_STACK entries of stack + 2 * EXACT_DEFER of list, shared by the wave.
+constexpr uint32_t EXACT_DEFER = 64;
+__device__ __forceinline__ bool closest_hit_exact_tlas_wave(const DScene &sc, const Ray &r, const RngKey &key, int segment, uint32_t *ws, uint32_t *blas_stack,
+                                                            float &best_t, uint32_t &best_obj, uint32_t &best_prim) {
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    const uint32_t lane = threadIdx.x & 63u;
+    const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+    uint32_t *dl = ws + EXACT_STACK;                                 // [EXACT_DEFER items][EXACT_DEFER positions]
+    bool have = false; float best = TMAX; uint32_t bobj = MISS, bprim = 0, bpos = 0;
+    int after = -1, nan_pos = -1; uint32_t nan_obj = 0, nan_prim = 0, nan_bits = 0;
+    auto take = [&](float t, uint32_t item, uint32_t prim, uint32_t pos) {
+        if (t != t) { if ((int)pos > nan_pos) { nan_pos = (int)pos; nan_obj = item; nan_prim = prim; nan_bits = __float_as_uint(t); } }
+        else if ((int)pos > after && (!have || t < best || (t == best && pos > bpos))) { have = true; best = t; bobj = item; bprim = prim; bpos = pos; }
+    };
+    for (bool second = false;; second = true) {
+        have = false; best = TMAX; bobj = MISS; bprim = 0; bpos = 0;
+        uint32_t nd = 0;                                             // listed mesh objects (wave-uniform)
+        uint32_t sp = 1;
+        if (lane == 0) ws[0] = 0u;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        while (sp > 0u) {
+            const int room = EXACT_STACK - EXACT_LEVELS - 8 - (int)sp;
+            uint32_t k = min(64u, sp);
+            if ((int)k > room) k = (uint32_t)max(1, room);
+            const bool active = lane < k;
+            const uint32_t node = active ? ws[sp - 1u - lane] : 0u;
+            sp -= k;
+            float4 lo = make_float4(0, 0, 0, 0), hi = lo;
+            if (active) { lo = sc.ref_tlas[2 * (size_t)node]; hi = sc.ref_tlas[2 * (size_t)node + 1]; }
+            const uint32_t A = __float_as_uint(lo.w), B = __float_as_uint(hi.w);
+            const bool hitb = active && hit_aabb(lo, hi, r.o, inv, TMIN, TMAX);
+            const bool branch = hitb && (A >> 30) == 0u;
+            const unsigned long long m = __ballot(branch);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (branch) {
+                const uint32_t at = sp + 2u * (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                ws[at] = A & NODE_MASK; ws[at + 1u] = node + 1u;
+            }
+            sp += 2u * (uint32_t)__popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const bool leaf = hitb && !branch;
+            for (uint32_t which = 0; which < 2u; which++) {          // a Leaf's item, then a DoubleLeaf's second
+                const bool on = leaf && (which == 0u || (A >> 30) == NODE_DOUBLE);
+                const uint32_t item = which ? B : (A & NODE_MASK);
+                bool defer = false;
+                if (on) {
+                    const Obj o = load_obj(sc.obj, item);
+                    defer = obj_kind(o) == 5u || (obj_kind(o) == 6u && obj_inner(o) == 5u);
+                    float t; uint32_t prim;
+                    if (!defer && hit_object<true, 1>(sc, o, item, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) take(t, item, prim, 2u * node + which);
+                }
+                const unsigned long long dm = __ballot(defer);
+                if (dm) {
+                    const uint32_t e = nd + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull));
+                    if (defer && e < EXACT_DEFER) { dl[e] = item; dl[EXACT_DEFER + e] = 2u * node + which; }
+                    nd += (uint32_t)__popcll(dm);
+                }
+            }
+        }
+        if (nd > EXACT_DEFER) return false;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (uint32_t e = 0; e < nd; e++) {                          // every lane the same object: its mesh walk is the wave's
+            const uint32_t item = dl[e], pos = dl[EXACT_DEFER + e];
+            const Obj o = load_obj(sc.obj, item);
+            float t; uint32_t prim;
+            if (hit_object<true, 2>(sc, o, item, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) take(t, item, prim, pos);
+        }
+        if (second || __ballot(nan_pos >= 0) == 0ull) break;
+        for (int d = 1; d < 64; d <<= 1) {        // the last NaN hit of the wave
+            const int op = __shfl_xor(nan_pos, d);
+            const uint32_t oo = (uint32_t)__shfl_xor((int)nan_obj, d), opr = (uint32_t)__shfl_xor((int)nan_prim, d), ob = (uint32_t)__shfl_xor((int)nan_bits, d);
+            if (op > nan_pos) { nan_pos = op; nan_obj = oo; nan_prim = opr; nan_bits = ob; }
+        }
+        after = nan_pos;
+    }
+    for (int d = 1; d < 64; d <<= 1) {
+        const bool oh = __shfl_xor((int)have, d) != 0;
+        const float ot = __shfl_xor(best, d);
+        const uint32_t oo = (uint32_t)__shfl_xor((int)bobj, d), opr = (uint32_t)__shfl_xor((int)bprim, d), opos = (uint32_t)__shfl_xor((int)bpos, d);
+        if (oh && (!have || ot < best || (ot == best && opos > bpos))) { have = true; best = ot; bobj = oo; bprim = opr; bpos = opos; }
+    }
+    if (!have && after >= 0) { best_t = __uint_as_float(nan_bits); best_obj = nan_obj; best_prim = nan_prim; return true; }
+    best_t = have ? best : TMAX; best_obj = have ? bobj : MISS; best_prim = have ? bprim : 0u;
+    return true;
+}
+
 template <int EXACT>   // 1: one ray per lane, 2: one ray per wave (hit_mesh_exact_lane / _wave)
 __device__ __forceinline__ void closest_hit_exact(const DScene &sc, const Ray &r, const RngKey &key, int segment, bool use_bvh, uint32_t *tlas_stack,
                                                   uint32_t *blas_stack, float &best_t, uint32_t &best_obj, uint32_t &best_prim) {
@@ -1932,6 +2024,10 @@ __device__ __forceinline__ void closest_hit_exact(const DScene &sc, const Ray &r
         }
         return;
     }
+    // a TLAS of a few objects (suzanne: 3) is walked faster node by node with every lane the same: the shared walk's rounds, its list
+    // and its reductions cost more than they save (k_extend_exact 40 -> 51 us per launch on suzanne; part2, 1 409 objects: 62 -> ~25)
+    if (EXACT == 2 && sc.n_objects > 16u && closest_hit_exact_tlas_wave(sc, r, key, segment, tlas_stack - (threadIdx.x & 63u), blas_stack, best_t, best_obj, best_prim)) return;
+    best_t = TMAX; best_obj = MISS; best_prim = 0;
     const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
     int sp = 0;
     uint32_t cur = 0; bool have = false;
@@ -2788,7 +2884,8 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
 }
 void launch_extend_exact(const LaunchCfg &c, const DScene &sc, const DFrame &f, const DPaths &in, float2 *hits, int segment, bool use_bvh) {
     // stacks sized by the reference trees' depths; the wave-shared mesh stack needs EXACT_STACK entries whatever the depth
-    const uint32_t tl = std::min<uint32_t>(c.ref_tlas_depth + 2u, EXACT_LEVELS);
+    // (the wave-shared TLAS stack + its list of mesh objects: EXACT_STACK + 2 * EXACT_DEFER entries)
+    const uint32_t tl = std::max<uint32_t>(std::min<uint32_t>(c.ref_tlas_depth + 2u, EXACT_LEVELS), (EXACT_STACK + 2u * EXACT_DEFER) / EXACT_WB);
     const uint32_t bl = std::max<uint32_t>(std::min<uint32_t>(c.ref_blas_depth + 2u, EXACT_LEVELS), EXACT_STACK / EXACT_WB);
     const size_t lds = (size_t)(tl + bl) * EXACT_WB * 4;
     // 8 single-wave workgroups per CU: most launches find an empty list, and dispatching 4 096 workgroups that only read a counter took 12 us
