@@ -1006,14 +1006,22 @@ struct BlockStream {
     // dynamic mode (dyn_ctr != nullptr): after its static range the wave takes further indices, one at a time, from a counter
     // (in LDS: the waves of a workgroup share the workgroup's queues)
     uint32_t *dyn_ctr; const uint32_t *dyn_counts; uint32_t dyn_first, dyn_end; bool dyn_done;
+    // unit mode (unit > 0; the LDS walks since round 3): the counter hands out UNITS of `unit` rays — queue index u / bpq, rays
+    // [u % bpq * unit, + unit) of it — instead of whole queues: a queue holds up to ~2 900 rays, 225 us of walking for the wave that
+    // took the last one while the other fifteen of its workgroup had nothing left (the LDS walks averaged 2.7 of 4 waves per SIMD).
+    // unit_counts: the workgroup's queue counts, staged in LDS (a unit beyond its queue's count is skipped for ~100 ns).
+    uint32_t unit, bpq; const uint32_t *unit_counts;
     uint32_t *ptotal;          // statistics: per-queue totals of parked rays (dynamic mode of k_blas_lds), or nullptr
     __device__ __forceinline__ void init(const uint32_t *counts, uint32_t first, uint32_t last, uint32_t stride_, uint32_t lane,
                                          uint32_t off_ = 0u, uint32_t mul_ = 1u) {
         q = q0 = first; q_end = last; q_off = off_; q_mul = mul_; stride = stride_; base = 0; n = 0; off = 0;
         cnt = (first + lane < last) ? counts[off_ + (first + lane) * mul_] : 0u;
-        dyn_ctr = nullptr; dyn_counts = counts; dyn_first = dyn_end = 0; dyn_done = true; ptotal = nullptr;
+        dyn_ctr = nullptr; dyn_counts = counts; dyn_first = dyn_end = 0; dyn_done = true; ptotal = nullptr; unit = 0; bpq = 1; unit_counts = nullptr;
     }
     __device__ __forceinline__ void init_dynamic(uint32_t *ctr, uint32_t first, uint32_t end) { dyn_ctr = ctr; dyn_first = first; dyn_end = end; dyn_done = first >= end; }
+    __device__ __forceinline__ void init_units(uint32_t *ctr, uint32_t n_queues, uint32_t unit_, const uint32_t *counts_in_lds) {
+        dyn_ctr = ctr; dyn_first = 0; dyn_end = n_queues; dyn_done = n_queues == 0; unit = unit_; bpq = (stride + unit_ - 1u) / unit_; unit_counts = counts_in_lds;
+    }
     // the next block of the stream: first slot and entry count (wave-uniform); false when the wave's queues are used up
     __device__ __forceinline__ bool next(uint32_t &b_base, uint32_t &b_n) {
         for (;;) {
@@ -1022,7 +1030,17 @@ struct BlockStream {
                 if (dyn_done) return false;
                 uint32_t v = 0;
                 if ((threadIdx.x & 63u) == 0) v = atomicAdd(dyn_ctr, 1u);
-                const uint32_t k = dyn_first + (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+                if (unit) {
+                    const uint32_t ku = u / bpq, b = u - ku * bpq;
+                    if (ku >= dyn_end) { dyn_done = true; return false; }
+                    const uint32_t nqu = q_off + ku * q_mul, cnt_q = unit_counts[ku], start = b * unit;
+                    if (ptotal && b == 0u && cnt_q && (threadIdx.x & 63u) == 0) ptotal[nqu] += cnt_q;
+                    if (start >= cnt_q) continue;
+                    base = nqu * stride + start; n = min(unit, cnt_q - start); off = 0;
+                    continue;
+                }
+                const uint32_t k = dyn_first + u;
                 if (k >= dyn_end) { dyn_done = true; return false; }
                 const uint32_t nq = q_off + k * q_mul;
                 n = dyn_counts[nq]; base = nq * stride; off = 0;
@@ -1704,6 +1722,10 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
 //    workgroups per CU lost as well).  What the LDS walks are short of is coherence, and neither change buys any.
 // ------------------------------------------------------------------------------------------------
 constexpr int LDS_WAVES = 16;                      // waves per workgroup of the LDS-resident walks
+constexpr uint32_t LDS_UNIT = 512;                 // rays a wave of theirs takes from the workgroup's counter at a time (BlockStream unit mode).
+// Measured (profiles/r03zi_lds_units_ab.txt, one batch in flight): whole queues -> 512: suzanne 73.8 -> 71.8 ms, part2 @16 10.6 -> 10.15;
+// with two batches in flight the other batch filled those gaps already (64.4 -> 64.8, 10.55 -> 10.45).  128: a grab per two
+// 64-ray rounds — counter, division, an emptied read-ahead — costs more than the balance gains: suzanne 64.8 -> 70 ms.
 template <bool LDS_TRIS>
 __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q,
                                                              uint32_t n_nodes, uint32_t n_tris, uint32_t levels) {
@@ -1718,13 +1740,13 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
     // neighbouring queues hold neighbouring pixels, and a run of them is several times heavier where it covers the mesh.
     // Wave i starts with k = i, further k come from the counter in LDS.
     const uint32_t n_k = (q.n_waves + gridDim.x - 1u - blockIdx.x) / gridDim.x;
+    uint32_t *lds_cnt = ctr + 4;                                          // the counts of this workgroup's queues
+    for (uint32_t k = threadIdx.x; k < n_k; k += LDS_WAVES * 64) lds_cnt[k] = park.pcount[blockIdx.x + k * gridDim.x];
     if (threadIdx.x == 0) *ctr = 0u;
     __syncthreads();
-    const uint32_t k_first = min(wib, n_k), k_last = min(k_first + 1u, n_k);
     BlockStream bs;
-    bs.init(park.pcount, k_first, k_last, park.stride, lane, blockIdx.x, gridDim.x);
-    bs.init_dynamic(ctr, LDS_WAVES, n_k);
-    if (k_first < k_last && lane == 0 && bs.cnt) park.ptotal[blockIdx.x + k_first * gridDim.x] += bs.cnt;
+    bs.init(park.pcount, 0u, 0u, park.stride, lane, blockIdx.x, gridDim.x);
+    bs.init_units(ctr, n_k, LDS_UNIT, lds_cnt);                           // units of LDS_UNIT rays from the counter in LDS
     bs.ptotal = park.ptotal;
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     float4 ca = make_float4(0, 0, 0, 0), na = ca, cm = ca, nm = ca; float2 cb = make_float2(0, 0), nb = cb;
@@ -1814,12 +1836,13 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
     uint16_t *stacks = reinterpret_cast<uint16_t *>(lds_nodes + (size_t)n_nodes * 4u);
     uint32_t *ctr = reinterpret_cast<uint32_t *>(stacks + (size_t)LDS_WAVES * levels * 64u);
     const uint32_t n_k = (q.n_waves + gridDim.x - 1u - blockIdx.x) / gridDim.x;     // queues blockIdx.x + k * gridDim.x (k_blas_lds)
+    uint32_t *lds_cnt = ctr + 4;                                          // the counts of this workgroup's queues
+    for (uint32_t k = threadIdx.x; k < n_k; k += LDS_WAVES * 64) lds_cnt[k] = q.wcount[(size_t)segment * q.n_waves + blockIdx.x + k * gridDim.x];
     if (threadIdx.x == 0) *ctr = 0u;
     __syncthreads();
-    const uint32_t k_first = min(wib, n_k), k_last = min(k_first + 1u, n_k);
     BlockStream bs;
-    bs.init(q.wcount + (size_t)segment * q.n_waves, k_first, k_last, q.cap, lane, blockIdx.x, gridDim.x);
-    bs.init_dynamic(ctr, LDS_WAVES, n_k);
+    bs.init(q.wcount + (size_t)segment * q.n_waves, 0u, 0u, q.cap, lane, blockIdx.x, gridDim.x);
+    bs.init_units(ctr, n_k, LDS_UNIT, lds_cnt);
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     float4 ca = make_float4(0, 0, 0, 0), na = ca; float2 cb = make_float2(0, 0), nb = cb; float cs = 0.f, ns = 0.f;
     auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float &st) {
@@ -2853,7 +2876,9 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
         else hipLaunchKernelGGL(k_extend_tlas_park, sg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
         // the whole BLAS in LDS when it fits next to sixteen 16-bit stacks (k_blas_lds), else node fetches from L2 (k_blas)
         const uint32_t bl = (uint32_t)c.blas_depth + 1u;
-        const size_t lds_blas = (size_t)c.blas_pair_nodes * 64 + (size_t)LDS_WAVES * bl * 64 * 2 + 16, lds_tris = (size_t)c.n_tris * 48;
+        const uint32_t lds_grid = std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES);       // workgroups of the LDS walks
+        const size_t lds_queue_counts = 16 + 4 * (size_t)((c.q.n_waves + lds_grid - 1) / lds_grid);                          // counter + the workgroup's queue counts
+        const size_t lds_blas = (size_t)c.blas_pair_nodes * 64 + (size_t)LDS_WAVES * bl * 64 * 2 + lds_queue_counts, lds_tris = (size_t)c.n_tris * 48;
         if (c.lds_trees && c.blas_pair_nodes > 0 && c.blas_pair_nodes < 32768u && c.max_tris < 32768u && lds_blas <= LDS_TREE_LIMIT) {
             if (lds_attr_needed(0)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
@@ -2869,7 +2894,8 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     }
     else if (use_bvh && c.tlas_refill) {
         // scenes without meshes: the whole TLAS in LDS when it fits next to sixteen 16-bit stacks
-        const size_t lds_tlas = (size_t)c.tlas_pair_nodes * 64 + (size_t)LDS_WAVES * (uint32_t)tl * 64 * 2 + 16;
+        const uint32_t lds_grid = std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES);
+        const size_t lds_tlas = (size_t)c.tlas_pair_nodes * 64 + (size_t)LDS_WAVES * (uint32_t)tl * 64 * 2 + 16 + 4 * (size_t)((c.q.n_waves + lds_grid - 1) / lds_grid);
         if (c.lds_trees && !c.has_mesh && sc.n_objects > TLAS_SCAN_MAX && c.tlas_pair_nodes < 32768u && sc.n_objects < 32768u && lds_tlas <= LDS_TREE_LIMIT) {
             if (lds_attr_needed(1)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
             hipLaunchKernelGGL(k_extend_tlas_lds, dim3(std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES)), dim3(LDS_WAVES * 64), lds_tlas, c.stream,
