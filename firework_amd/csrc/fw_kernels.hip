@@ -1725,7 +1725,10 @@ constexpr int LDS_WAVES = 16;                      // waves per workgroup of the
 constexpr uint32_t LDS_UNIT = 512;                 // rays a wave of theirs takes from the workgroup's counter at a time (BlockStream unit mode).
 // Measured (profiles/r03zi_lds_units_ab.txt, one batch in flight): whole queues -> 512: suzanne 73.8 -> 71.8 ms, part2 @16 10.6 -> 10.15;
 // with two batches in flight the other batch filled those gaps already (64.4 -> 64.8, 10.55 -> 10.45).  128: a grab per two
-// 64-ray rounds — counter, division, an emptied read-ahead — costs more than the balance gains: suzanne 64.8 -> 70 ms.
+// 64-ray rounds — counter, division, an emptied read-ahead — costs more than the balance gains: suzanne 64.8 -> 70 ms — but where the
+// queues themselves hold 512 rays (small frames) 128 is the better unit: random_spheres 1.97 -> 1.88 ms, part2 @16 10.45 -> 10.3.
+// Hence a quarter of the queue, between 128 and 512:
+__host__ __device__ inline uint32_t lds_unit(uint32_t queue_slots) { const uint32_t u = (queue_slots / 4u) & ~63u; return u < 128u ? 128u : (u > LDS_UNIT ? LDS_UNIT : u); }
 template <bool LDS_TRIS>
 __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q,
                                                              uint32_t n_nodes, uint32_t n_tris, uint32_t levels) {
@@ -1746,7 +1749,7 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
     __syncthreads();
     BlockStream bs;
     bs.init(park.pcount, 0u, 0u, park.stride, lane, blockIdx.x, gridDim.x);
-    bs.init_units(ctr, n_k, LDS_UNIT, lds_cnt);                           // units of LDS_UNIT rays from the counter in LDS
+    bs.init_units(ctr, n_k, lds_unit(park.stride), lds_cnt);               // units of rays from the counter in LDS
     bs.ptotal = park.ptotal;
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     float4 ca = make_float4(0, 0, 0, 0), na = ca, cm = ca, nm = ca; float2 cb = make_float2(0, 0), nb = cb;
@@ -1842,7 +1845,7 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
     __syncthreads();
     BlockStream bs;
     bs.init(q.wcount + (size_t)segment * q.n_waves, 0u, 0u, q.cap, lane, blockIdx.x, gridDim.x);
-    bs.init_units(ctr, n_k, LDS_UNIT, lds_cnt);
+    bs.init_units(ctr, n_k, lds_unit(q.cap), lds_cnt);
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     float4 ca = make_float4(0, 0, 0, 0), na = ca; float2 cb = make_float2(0, 0), nb = cb; float cs = 0.f, ns = 0.f;
     auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float &st) {
