@@ -1762,6 +1762,7 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
     bool act = false, have = false;
     uint32_t slot = 0, obj = 0, tri_base = 0, bcode = MISS, mtri = 0, cur = REF_DONE;
     float bt = TMAX, mbest = TMAX;
+    uint32_t pend = REF_DONE;                                       // a triangle put aside while its lane walks on (REF_DONE: none)
     V3 ro = mk(0, 0, 0), inv = ro;
     TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
     LdsStack16 st{stacks + (size_t)wib * levels * 64u + lane, 0};
@@ -1796,6 +1797,11 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
 
         const uint32_t n_act = (uint32_t)__popcll(__ballot(act));
         for (;;) {
+            // A lane that holds a triangle but has more of its tree on the stack puts the triangle aside and walks on (one aside
+            // at most): more lanes walk in the node loop, more lanes hold a triangle when the wave turns to the triangles, for a few
+            // node visits that the untested triangle would have culled.  Same tests, same winner.  suzanne 64.7 -> 63.4 ms, @64 9.99 ->
+            // 9.78 (three interleaved pairs, profiles/r03zn_pending_leaf_ab.txt; other exit rules and refill thresholds with it: worse).
+            if (act && (cur & REF_LEAF) && cur != REF_DONE && pend == REF_DONE && st.sp > 0) { pend = cur; cur = st.pop(); }
             const bool walking = act && !(cur & REF_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
@@ -1804,10 +1810,12 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
             // (suzanne @64 10.1 -> 9.9 ms; the TLAS walk of part2 gains nothing from the same and keeps one)
             if (act && !(cur & REF_LEAF)) cur = pair_step(lds_nodes, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
         }
-        if (act && (cur & REF_LEAF)) {
-            if (cur != REF_DONE) {
-                const uint32_t item = cur & NODE_MASK;
-                cur = st.sp ? st.pop() : REF_DONE;
+        for (int pass = 0; pass < 2; pass++) {                         // the triangles put aside, then the ones held
+            uint32_t item = REF_DONE;
+            if (pass == 0) { if (act && pend != REF_DONE) { item = pend & NODE_MASK; pend = REF_DONE; } }
+            else if (act && (cur & REF_LEAF) && cur != REF_DONE) { item = cur & NODE_MASK; cur = st.sp ? st.pop() : REF_DONE; }
+            if (__ballot(item != REF_DONE) == 0ull) continue;
+            if (item != REF_DONE) {
                 const float4 *tp = (LDS_TRIS ? lds_tris : sc.tri) + 3 * (size_t)(tri_base + item);
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, b0, b1, b2;
@@ -1815,6 +1823,8 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
                     if (!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) { have = true; mbest = t; mtri = item; }
                 }
             }
+        }
+        if (act && (cur & REF_LEAF)) {
             if (cur == REF_DONE) {
                 const uint32_t bobj = bcode == MISS ? MISS : (bcode >> sc.prim_bits);
                 if (have && (bobj == MISS || mbest < bt || (mbest == bt && sc.obj_rank[obj] > sc.obj_rank[bobj]))) { bt = mbest; bcode = (obj << sc.prim_bits) | mtri; }
@@ -1915,6 +1925,8 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
         const bool busy = slot != IDLE && cur != REF_DONE;
         const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
         for (;;) {
+            // (An object put aside like k_blas_lds's triangle — FW_PEND_OBJ in round 3 — lost: part2 @64 33.8 -> 37.6 ms, random_spheres
+            // 1.92 -> 2.05: an object found early culls much of the walk that its lane would do meanwhile.)
             const bool walking = busy && !(cur & REF_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
