@@ -954,7 +954,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         if (linear_rgb) { need(ws->out_linear, (size_t)n_pix * 12); d_linear = (float *)ws->out_linear.p; }
     }
     if (rc) return rc;
-    while (ws->events.size() < 3 + (size_t)n_batches) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, ws->events.size() < 2 ? hipEventDefault : hipEventDisableTiming)); ws->events.push_back(e); }
+    while (ws->events.size() < 3 + 2 * (size_t)n_batches) {      // [3 + b] accumulated, [3 + n_batches + b] batch b's first k_extend finished (stagger)
+         hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, ws->events.size() < 2 ? hipEventDefault : hipEventDisableTiming)); ws->events.push_back(e); }
 
     if (ws->ev_upload) HIPCHK(hipStreamWaitEvent(stream, ws->ev_upload, 0));     // the scene's upload kernel (null stream)
     if (p->pixel_ids) HIPCHK(hipMemcpyAsync(ws->pixel_ids.p, p->pixel_ids, (size_t)n_pix * 4, hipMemcpyHostToDevice, stream));
@@ -1025,6 +1026,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // Off by default: the frame is VALU-bound, not HBM-bound, and the fused kernel's lower occupancy costs more than the
     // bytes save (cornell 62.0 vs 55.5 ms, hdri 35.5 vs 38.5 ms, 1/8-frame shares 9.2 vs 8.3 ms).  Never with parked mesh rays.
     const bool fused = fused_req;
+    const bool stagger = n_lanes > 1 && getenv("FIREWORK_STAGGER") != nullptr;   // experiment: batch b's first k_extend waits for batch b-1's
 
     // FIREWORK_DUMP_PATH=file, one pixel x one sample: after every k_extend the path's ray, state and hit record are copied out
     // and written to `file` as 11 x 16 floats (ray_a[4] ray_b[2] state[4] hit[2] alive pad[3]) behind a header of 8 u32
@@ -1072,7 +1074,9 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
             if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
             else {
+                if (stagger && seg == 0 && b > 0) HIPCHK(hipStreamWaitEvent(ls, ws->events[3 + n_batches + b - 1], 0));   // start half a segment behind the batch before
                 timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park); });
+                if (stagger && seg == 0) HIPCHK(hipEventRecord(ws->events[3 + n_batches + b], ls));
                 // the rays whose result depends on how the trees are walked (DExact), walked the reference's way: their hit records replaced
                 if (exact_mode) timed(1, [&] { fw::launch_extend_exact(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh); });
                 if (dump_one) {     // debug (tools/diverge.py): the one path of this call sits in slot 0 of wave 0 in every segment
