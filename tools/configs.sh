@@ -17,4 +17,4 @@ run C2_cornell_box 3 1
 run C3_suzanne 2 1
 run C4a_hdri_test 2 1
 run C4b_volume_test 2 1
-run C5_part2_all 1 0
+run C5_part2_all 2 1
