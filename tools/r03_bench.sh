@@ -9,11 +9,8 @@ echo "== cornell lanes A/B"
 for i in 1 2 3; do for n in 1 2; do FIREWORK_STREAMS=$n timeout -k 10 200 python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-one-shot --no-kernel-timing 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('streams=$n ms', round(d['ms_per_step'],2))"; done; done 2>&1 | tee $OUT/lanes_ab.txt
 echo "== Infinity-Cache-sized batches (paths per batch x streams)"
 for ppb in 2097152 8388608 33554432; do for n in 2 4; do FIREWORK_STREAMS=$n FIREWORK_PATHS_PER_BATCH=$ppb timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-shot --no-kernel-timing 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ppb=$ppb streams=$n ms', round(d['ms_per_step'],2))"; done; done 2>&1 | tee $OUT/mall_batches.txt
-echo "== two rays per lane (FIREWORK_BLAS2=0 is one): suzanne @64 and full"
 R=$PWD
 run() { timeout -k 10 200 python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-one-shot $2 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('kernel_ms_per_step',{}); print('$1', 'ms', round(d['ms_per_step'],2), 'excl', round(d['schedule']['exclusive_pass_ms_per_step'],2), 'ext', round(k.get('ms_extend',0),2), 'shd', round(k.get('ms_shade',0),2))"; }
-for i in 1 2 3; do run "blas2" "--config C3_suzanne --spp 64"; FIREWORK_BLAS2=0 run "blas1" "--config C3_suzanne --spp 64"; done 2>&1 | tee $OUT/blas2_ab64.txt
-for i in 1 2; do run "blas2" "--config C3_suzanne"; FIREWORK_BLAS2=0 run "blas1" "--config C3_suzanne"; done 2>&1 | tee $OUT/blas2_ab_full.txt
 echo "== k_shade list (FIREWORK_NO_SHADE_DEFER=1 is round 2's kernel): part2 @16, hdri @64, random_spheres, volume @64, cornell @128"
 for cfg in "--config C5_part2_all --spp 16" "--config C4a_hdri_test --spp 64" "--config C1_random_spheres" "--config C4b_volume_test --spp 64" "--spp 128"; do
   for i in 1 2; do run "list   $cfg" "$cfg"; FIREWORK_NO_SHADE_DEFER=1 run "inline $cfg" "$cfg"; done
