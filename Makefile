@@ -16,6 +16,13 @@ $(LIB): $(SRC) $(HDR)
 	mkdir -p firework_amd/lib
 	$(HIPCC) $(HIPFLAGS) -x hip -shared -o $@ $(SRC)
 
+# the A/B build: the product plus the alternative kernels that were measured slower and their switches (fw_device.h: FW_AB);
+# tests/ and tools/ load it with FIREWORK_LIB=firework_amd/lib/variants/lib_ab.so
+ab: firework_amd/lib/variants/lib_ab.so
+firework_amd/lib/variants/lib_ab.so: $(SRC) $(HDR)
+	mkdir -p firework_amd/lib/variants
+	$(HIPCC) $(HIPFLAGS) -DFW_AB=1 -x hip -shared -o $@ $(SRC)
+
 oracle:
 	$(MAKE) -C oracle
 
@@ -29,4 +36,4 @@ clean:
 	rm -f $(LIB) examples/cornell_box
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle examples clean
+.PHONY: all ab oracle examples clean

@@ -244,9 +244,9 @@ def main():
 
 
 def exclusive_pass(tr, keys, frames):
-    """`frames` frames with one batch in flight (FIREWORK_STREAMS=1): per-kernel HIP-event times that belong to one kernel each."""
-    prev = os.environ.get("FIREWORK_STREAMS")
-    os.environ["FIREWORK_STREAMS"] = "1"
+    """`frames` frames with one batch in flight (option STREAMS=1): per-kernel HIP-event times that belong to one kernel each."""
+    from firework_amd import _lib
+    _lib.set_option("STREAMS", "1")
     def frame():          # this rank's share, no collective (only rank 0 runs the exclusive pass)
         return tr.scene.render(tr.renderer, pixel_ids=tr.tg.ids, out_device_ptrs=(tr.tg.local.data_ptr(), None, None))
     try:
@@ -262,10 +262,7 @@ def exclusive_pass(tr, keys, frames):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / frames
     finally:
-        if prev is None:
-            del os.environ["FIREWORK_STREAMS"]
-        else:
-            os.environ["FIREWORK_STREAMS"] = prev
+        _lib.set_option("STREAMS", os.environ.get("FIREWORK_STREAMS"))      # back to what the library was loaded with
     acc["frames"] = frames
     return acc, ms
 

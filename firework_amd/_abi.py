@@ -1,7 +1,7 @@
 """ctypes mirror of include/firework_hip.h (the C ABI).  Field order and types must match the header."""
 import ctypes as C
 
-FW_ABI_VERSION = 5
+FW_ABI_VERSION = 6
 FW_MAX_SEGMENTS = 11
 
 # fw_status

@@ -61,6 +61,10 @@ def load():
     lib.fw_selftest_arith.argtypes = [C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.fw_selftest_libm.restype = C.c_int
     lib.fw_selftest_libm.argtypes = [C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.fw_set_option.restype = C.c_int
+    lib.fw_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    lib.fw_selftest_wide_bvh.restype = C.c_int
+    lib.fw_selftest_wide_bvh.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     if lib.fw_abi_version() != A.FW_ABI_VERSION:
         raise FireworkError(A.FW_ERR_BAD_ARG, "ABI version mismatch between _abi.py and libfirework_hip.so")
     _lib = lib
@@ -70,6 +74,45 @@ def load():
 def _check(lib, st):
     if st != A.FW_OK:
         raise FireworkError(st, f"{lib.fw_strerror(st).decode()} | {lib.fw_last_error().decode()}")
+
+
+def set_option(name, value=None):
+    """fw_set_option: one runtime switch of the library (FIREWORK_<NAME>; the environment itself is read once, at load).
+    value None = back to the default; name None = back to what the environment said at load time."""
+    lib = load()
+    _check(lib, lib.fw_set_option(None if name is None else str(name).encode(), None if value is None else str(value).encode()))
+
+
+class options:
+    """with _lib.options(FIREWORK_BVH="median", NO_DEFER="1"): ...  — switches set for the block, defaults restored after it."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_option(k, None)
+        return False
+
+
+def has_ab():
+    """True for the A/B build (make ab: -DFW_AB=1), which also carries the measured-slower alternative kernels and their switches."""
+    return hasattr(load(), "fw_debug_ab")
+
+
+def selftest_wide_bvh(boxes, fmt):
+    """fw_selftest_wide_bvh (CPU only): wide-node builder + invariant check over (n, 6) float32 item boxes.  -> (violations, stats)"""
+    lib = load()
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+    bad = C.c_uint32()
+    stats = (C.c_uint32 * 4)()
+    _check(lib, lib.fw_selftest_wide_bvh(b.ctypes.data, b.shape[0], int(fmt), C.byref(bad), stats))
+    return int(bad.value), dict(nodes=int(stats[0]), leaves=int(stats[1]), free_slots=int(stats[2]), depth=int(stats[3]))
 
 
 def selftest_arith(n, seed=1, mode=0, device=0):

@@ -4,6 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// FW_AB=1 (make ab): the A/B build, which also carries the alternatives that were measured slower and taken out of the product —
+// k_bounce (one launch per segment), the chunked k_extend_bvh, k_shade's list of expensive materials — with their switches, so
+// that the bit-identity tests and tools/ can still run them.  The product build (0) has neither the kernels nor the switches.
+#ifndef FW_AB
+#define FW_AB 0
+#endif
+
 namespace fw {
 
 // ---- object record: 6 x float4 = 96 B, 16-B aligned (one RenderObjectInternal, scene.rs:165-174,
@@ -47,6 +54,18 @@ enum : uint32_t {
 //   A>>30 == 1: Leaf        item = A & 0x3fffffff
 //   A>>30 == 2: DoubleLeaf  items = A & 0x3fffffff, B
 constexpr uint32_t REF_LEAF = 0x80000000u, REF_DONE = 0xffffffffu;
+// ---- BVH as walked by the LDS-resident kernels since round 4: WIDE NODES, four children each (fw_runtime.cpp: wide_convert,
+//   collapsed from the same binary tree as the pair nodes).  References are 16 bits: bit 15 = leaf (item in the low 15 bits),
+//   otherwise a wide node's index; W_DONE ends a walk.  A free slot repeats child 0's reference behind a box no finite ray hits.
+//   WIDE_F32, 28 dwords (112 B), SoA by plane so that a lane fetches the near / far plane of all four children with one
+//   ds_read_b128 at an offset its ray's signs select (no per-box selects):
+//       lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4] | ref0|ref1<<16  ref2|ref3<<16  -  -
+//   WIDE_Q8, 12 dwords (48 B): planes quantised to 8 bits, plane = fma(q, 2^(e-127), origin) per axis, rounded outward on the host
+//   with that very expression (a superset of the exact box under the same slab arithmetic: such boxes only cull):
+//       origin.xyz  e.x|e.y<<8|e.z<<16 | qlo.x[4] qlo.y[4] qlo.z[4]  ref0|ref1<<16 | qhi.x[4] qhi.y[4] qhi.z[4]  ref2|ref3<<16
+constexpr int WIDE_NONE = 0, WIDE_F32 = 1, WIDE_Q8 = 2;
+constexpr uint32_t WIDE_F32_DW = 28, WIDE_Q8_DW = 12;
+constexpr uint32_t W_LEAF = 0x8000u, W_DONE = 0xffffu;
 constexpr uint32_t MF_NEEDS_UV = 1u << 8;    // the material's texture tree contains an ImageTexture
 constexpr uint32_t MF_TEX_CONST = 1u << 9;   // texture is a ConstantTexture, colour inlined in the record
 constexpr uint32_t NODE_LEAF = 1u, NODE_DOUBLE = 2u, NODE_MASK = 0x3fffffffu;
@@ -75,10 +94,14 @@ struct DScene {
     const float4 *blas;
     const float4 *tri;
     const float4 *tri_nrm;   // same indexing as tri; valid only for meshes with OF_MESH_ATTR
+    const float4 *tri_gate;   // per triangle (same indexing as tri): box (2 x float4) of its leaf node in the REFERENCE tree of its mesh — the box
+                              // the reference's walk must pass to test the triangle (tri_gate_ok)
     const uint32_t *tri_rank; // in-order rank of each triangle in the REFERENCE tree of its mesh (tie-breaking)
     const uint32_t *obj_rank; // same for objects in the reference TLAS
     const float4 *obj_gate;   // per object: box (2 x float4) of its leaf node in the reference TLAS (used with OF_GATE)
-    const float4 *obj_cull;   // per object: enclosing world box (2 x float4) for the camera-ray pre-test of the linear scan
+    const float4 *obj_cull;   // per object: enclosing world box (2 x float4) of the object itself: the pre-tests of the linear scan
+    const float4 *obj_leaf;   // per object: its box in the WALKED trees = its own world box (a gated object: its reference leaf-node box united
+                              // with bounds that enclose it): what k_extend_scan / hoisted_hits test before the object
     const float4 *mat;
     const float4 *tex;
     const uint8_t *images;
@@ -91,6 +114,11 @@ struct DScene {
     const float4 *ref_tlas;   // the REFERENCE trees (host FlatBvh format below: 2 x float4 per node, DFS order), walked only by
     const float4 *ref_blas;   // k_extend_exact; ref_blas holds every mesh's tree, child indices relative to the mesh's first node
     const uint32_t *obj_ref_blas;   // per object: first node of its mesh's reference tree in ref_blas (meshes and media around meshes)
+    const uint32_t *wblas;    // WIDE nodes of every mesh (one array, node indices global to it) and of the TLAS; null when the scene
+    const uint32_t *wtlas;    // has no tree the LDS-resident wide walks take (launch_extend then keeps the pair-node kernels)
+    const uint32_t *obj_wroot;    // per object: root reference of its mesh's wide tree (16-bit convention)
+    uint32_t wtlas_root;
+    float soft_shear;         // the SOFT class (fw_kernels.hip: soft_direction): |d_kz| < soft_shear * max|d| walks without culling; 0: off
     uint32_t n_hoisted;       // objects kept OUT of the walked TLAS because nearly every ray meets their box (part2's fog sphere
     uint32_t hoisted[4];      // around the whole scene): tested for every ray, wave-uniformly, before the walk (hoisted_hits)
     DEnv env;
@@ -114,6 +142,7 @@ struct DExact {
     uint32_t mode;
     uint32_t n_frames;            // distinct rotations of mesh objects (<= 4), rows of rotation_mat
     float frames[4][9];
+    float shear;                  // mode & 1: |d_kz| < shear * max|d_i| is ill-conditioned (2^-10)
     float far_c[3], far_r;        // centre of the small-object cluster, distance beyond which an origin is "far"
     float box_lo[3], box_hi[3];   // the cluster's box, inflated
     uint32_t *slots[2];           // the flagged rays' queue slots: list of segment s in slots[s & 1] (filled by k_raygen / k_shade(s-1), read by k_extend_exact(s))
@@ -144,6 +173,8 @@ struct DFrame {
     uint32_t hit4;                // 4-byte hit records (the code only): k_shade recomputes t.  Linear scan, scenes of spheres / rects / Rect3d only
     uint32_t pinhole0;            // aperture 0: every camera ray starts at cam_pos, segment-0 rays are stored as 16 B (direction only)
     float cam_pos[3];
+    uint32_t chain_bits;          // != 0: 8-byte path state (fw_kernels.hip: load_state_chain): bits per material id in the chain; every material's
+                                  // attenuation is a constant of the material and 10 ids fit 32 bits (host: fw_scene.chain_bits)
     DExact ex;                    // which rays are traced a second time by the literal reference walk
 };
 
@@ -175,7 +206,7 @@ struct DPark {
 
 // Bytes per record of the streams above: what fw_stats.bytes_* (the layout's own algorithmic HBM bytes) are computed from,
 // kept next to the layout so that the two change together.
-constexpr uint32_t B_RAY = 24, B_RAY_PINHOLE0 = 16, B_STATE = 16, B_HIT = 8, B_HIT4 = 4, B_DEPOSIT = 16, B_PARK = 40, B_ACCUM = 16;
+constexpr uint32_t B_RAY = 24, B_RAY_PINHOLE0 = 16, B_STATE = 16, B_STATE_CHAIN = 8, B_HIT = 8, B_HIT4 = 4, B_DEPOSIT = 16, B_PARK = 40, B_ACCUM = 16;
 
 constexpr uint32_t MISS = 0xffffffffu;
 constexpr int MAX_SEGMENTS = 11;
@@ -198,6 +229,8 @@ struct LaunchCfg {
     int shade_mode;       // k_shade: 0 everything in line, 1 the scene has no expensive material / environment (the cheap loop alone), 2 expensive paths go through a list (FIREWORK_SHADE_LIST=1: measured slower, kept for A/B)
     int exact_form;               // k_extend_exact: 0 = by list length, 1 = one ray per lane, 2 = one ray per wave (FIREWORK_EXACT_FORM=lane|wave: tests)
     uint32_t ref_tlas_nodes, ref_blas_nodes, ref_tlas_depth, ref_blas_depth;   // the reference trees k_extend_exact walks (nodes of 32 B)
+    int wblas_fmt, wtlas_fmt;     // WIDE_NONE / WIDE_F32 / WIDE_Q8: the encoding of DScene.wblas / wtlas (FIREWORK_WIDE=0: none; =q8 / =f32 force one)
+    uint32_t wblas_nodes, wtlas_nodes, wblas_depth, wtlas_depth;   // wide nodes; wide nodes on the longest root-to-leaf path
     bool tlas_refill;     // refilling walks: k_extend_tlas (no meshes) / k_extend_tlas_park + k_blas (meshes); FIREWORK_TLAS_REFILL=0: the chunked k_extend_bvh
 };
 constexpr size_t LDS_TREE_LIMIT = 160 * 1024;   // the whole LDS of a CU: one workgroup of the LDS-resident walks per CU

@@ -224,15 +224,55 @@ __device__ __forceinline__ float4 load_state(const DPaths &in, uint32_t i, int s
     if (segment == 0) return make_float4(1.f, 1.f, 1.f, __uint_as_float(i));
     return qld(&in.state[i]);
 }
+// CHAIN state (DFrame.chain_bits != 0), 8 bytes per path instead of 16: (the materials the path has scattered on so far, chain_bits
+// bits per segment, segment 0 lowest | home slot).  Where every attenuation is a constant of its material (no texture that varies:
+// cornell, suzanne, hdri, volume) the running product beta.rgb is replaced by the material ids, and the ONE path in 30 that ends in
+// light multiplies them out when it deposits — back to front, a0 * (a1 * (... * emit)), which is the association of the reference's
+// recursion (render.rs:23-28): the pre-gamma sample sums are then the oracle's bit for bit, and k_shade, which is bound by its queue
+// streams, moves 8 bytes less per ray in each direction.  Returned as (chain bits, -, -, home bits).
+__device__ __forceinline__ float4 load_state_chain(const DPaths &in, uint32_t i, int segment) {
+    if (segment == 0) return make_float4(0.f, 0.f, 0.f, __uint_as_float(i));
+    const float2 v = qld(&reinterpret_cast<const float2 *>(in.state)[i]);
+    return make_float4(v.x, 0.f, 0.f, v.y);
+}
+// the home slot alone (bits, as a float), for the kernels that need the path's RNG key (a medium's draw) and nothing else of the state
+__device__ __forceinline__ float load_home(const DPaths &in, uint32_t i, const DFrame &f, int segment) {
+    if (segment == 0) return __uint_as_float(i);
+    if (f.chain_bits) return reinterpret_cast<const float2 *>(in.state)[i].y;
+    return in.state[i].w;
+}
 
 // ------------------------------------------------------------------------------------------------
 // The exact walk's flag rule (fw_device.h DExact): does this ray's result depend on how the trees are walked?
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool ill_direction(float dx, float dy, float dz) {
+__device__ __forceinline__ bool ill_direction(float dx, float dy, float dz, float shear) {
     // util.rs:104-118 picks the SIGNED largest component as the shear axis of mesh.rs:147-162
     const float dk = dx > dy ? (dz > dx ? dz : dx) : (dz > dy ? dz : dy);
     const float am = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
-    return fabsf(dk) < am * (1.0f / 1024.0f);
+    return fabsf(dk) < am * shear;        // DExact.shear: 2^-10 (option EXACT_SHEAR_LOG2)
+}
+// The SOFT class (round 4).  Between "ill-conditioned enough for the exact list" (2^-10) and well-conditioned lies a band of rays
+// whose triangle hits carry errors of ~(max|d| / |d_kz|) ulps: a t that can precede the entry of its own triangle's box by more
+// than cull_bound's slack.  The reference never culls, so it finds such a hit; a walk that culls against the best t so far may not
+// (two paths of suzanne's 1.1e9 at 512 spp, shear ratios 2^-7.2 and 2^-9.97: tools/full_parity.py, gpurun_out/r04b).  A ray in this
+// band — 2 % of uniformly distributed directions — is walked WITHOUT culling: with the item boxes being the reference's leaf-node
+// boxes (fw_runtime.cpp) the walk then tests exactly the reference's set of items, and the smallest t with the rank rule on a tie
+// is the reference's winner.  Costs such a ray a few times its culled walk, inside the ordinary kernels.
+constexpr float NO_CULL = 3.40282347e+38f;
+// shear = DScene.soft_shear (2^-5 unless option SOFT_SHEAR_LOG2 says otherwise; 0: the class is off)
+__device__ __forceinline__ bool soft_direction(float dx, float dy, float dz, float shear) {
+    const float dk = dx > dy ? (dz > dx ? dz : dx) : (dz > dy ? dz : dy);
+    const float am = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz));
+    return fabsf(dk) < am * shear;
+}
+// at the level of the TLAS: in the world frame or in the frame of any rotated mesh (DExact.frames)
+__device__ __forceinline__ bool soft_ray(const DExact &ex, V3 d, float shear) {
+    if (soft_direction(d.x, d.y, d.z, shear)) return true;
+    for (uint32_t k = 0; k < ex.n_frames; k++) {
+        const float *m = ex.frames[k];
+        if (soft_direction(m[0] * d.x + m[3] * d.y + m[6] * d.z, m[1] * d.x + m[4] * d.y + m[7] * d.z, m[2] * d.x + m[5] * d.y + m[8] * d.z, shear)) return true;
+    }
+    return false;
 }
 // A ray with a NaN in it passes every box (the slab test's min / max drop NaNs) and "hits" triangles with a NaN t that no comparison
 // rejects (mesh.rs:164-177) and that `!(best < t)` lets replace and be replaced: its result depends on the order of the tests like
@@ -247,10 +287,10 @@ __device__ __forceinline__ bool needs_exact(const DExact &ex, float ox, float oy
     if (ex.mode & 4u) return true;
     if (nan_ray(ox, oy, oz, dx, dy, dz)) return true;
     if (ex.mode & 1u) {
-        if (ill_direction(dx, dy, dz)) return true;
+        if (ill_direction(dx, dy, dz, ex.shear)) return true;
         for (uint32_t k = 0; k < ex.n_frames; k++) {            // inv_rotation_mat * d = rows of rotation_mat as columns (rot_inv)
             const float *m = ex.frames[k];
-            if (ill_direction(m[0] * dx + m[3] * dy + m[6] * dz, m[1] * dx + m[4] * dy + m[7] * dz, m[2] * dx + m[5] * dy + m[8] * dz)) return true;
+            if (ill_direction(m[0] * dx + m[3] * dy + m[6] * dz, m[1] * dx + m[4] * dy + m[7] * dz, m[2] * dx + m[5] * dy + m[8] * dz, ex.shear)) return true;
         }
     }
     if (ex.mode & 2u) {
@@ -642,16 +682,49 @@ __device__ __forceinline__ bool hit_aabb(float4 lo, float4 hi, V3 o, V3 inv, flo
     tmin = fmaxf(tmin, inv.z < 0.f ? t1 : t0); tmax = fminf(tmax, inv.z < 0.f ? t0 : t1);
     return tmax > tmin;
 }
-// the same test, also returning where the ray enters the box (clamped to tmin): orders the two children of a pair node
-__device__ __forceinline__ bool hit_aabb_entry(float4 lo, float4 hi, V3 o, V3 inv, float tmin, float tmax, float &entry) {
-    float t0 = (lo.x - o.x) * inv.x, t1 = (hi.x - o.x) * inv.x;
-    tmin = fmaxf(tmin, inv.x < 0.f ? t1 : t0); tmax = fminf(tmax, inv.x < 0.f ? t0 : t1);
-    t0 = (lo.y - o.y) * inv.y; t1 = (hi.y - o.y) * inv.y;
-    tmin = fmaxf(tmin, inv.y < 0.f ? t1 : t0); tmax = fminf(tmax, inv.y < 0.f ? t0 : t1);
-    t0 = (lo.z - o.z) * inv.z; t1 = (hi.z - o.z) * inv.z;
-    tmin = fmaxf(tmin, inv.z < 0.f ? t1 : t0); tmax = fminf(tmax, inv.z < 0.f ? t0 : t1);
+// The box test of the WALKS (round 4): aabb.rs:30-50 with the planes chosen by the ray's signs before the arithmetic, the entry
+// distance returned (clamped to tmin: it orders the children and is what culling compares), and the EXIT planes multiplied by
+// inv_hi = inv * (1 + 2^-12) instead of inv (relaxed(): three more registers per ray, no more instructions per box).
+// Why relaxed.  Which items the reference tests is decided by its own leaf-node boxes (tri_gate_ok / obj_gate_ok below, exact);
+// the walked trees only have to REACH every item that rule admits and that the item test accepts.  Such an item can lie a hair
+// outside its own, tight box: a ray that touches a box exactly at an edge (entry == exit: `tmax > tmin` fails, the union behind a
+// DoubleLeaf passes), a sphere whose discriminant is rounding noise at its silhouette (the ray may miss it by 2^-24 L^2 / r and still
+// "hit": 1.2e-4 for r = 0.1 seen from L = 14), a triangle hit carrying (max|d| / |d_kz|) ulps.  Relative to the distance these are
+// <= 2^-12 for every ray that is not on the exact list (far rule: L < 2048 r; shear rule: < 2^10), so a box admits every ray whose
+// exit is within that of its entry.  Four such paths in part2's 1.8e9 at 256 spp, one in teapot's 2.7e8 (gpurun_out/r04a, r04b).
+constexpr float GATE_RELAX = 1.0f + 1.0f / 4096.0f;
+__device__ __forceinline__ V3 relaxed(V3 inv) { return mk(inv.x * GATE_RELAX, inv.y * GATE_RELAX, inv.z * GATE_RELAX); }
+__device__ __forceinline__ bool hit_aabb_entry(float4 lo, float4 hi, V3 o, V3 inv, V3 inv_hi, float tmin, float tmax, float &entry) {
+    const bool sx = inv.x < 0.f, sy = inv.y < 0.f, sz = inv.z < 0.f;
+    tmin = fmaxf(tmin, ((sx ? hi.x : lo.x) - o.x) * inv.x); tmax = fminf(tmax, ((sx ? lo.x : hi.x) - o.x) * inv_hi.x);
+    tmin = fmaxf(tmin, ((sy ? hi.y : lo.y) - o.y) * inv.y); tmax = fminf(tmax, ((sy ? lo.y : hi.y) - o.y) * inv_hi.y);
+    tmin = fmaxf(tmin, ((sz ? hi.z : lo.z) - o.z) * inv.z); tmax = fminf(tmax, ((sz ? lo.z : hi.z) - o.z) * inv_hi.z);
     entry = tmin;
     return tmax > tmin;
+}
+// mesh.rs:221-242: a triangle's own box (a flat axis padded by 0.001 on both sides), for tri_gate_ok
+__device__ __forceinline__ void triangle_box(V3 p0, V3 p1, V3 p2, float4 &lo, float4 &hi) {
+    lo = make_float4(fminf(fminf(p0.x, p1.x), p2.x), fminf(fminf(p0.y, p1.y), p2.y), fminf(fminf(p0.z, p1.z), p2.z), 0.f);
+    hi = make_float4(fmaxf(fmaxf(p0.x, p1.x), p2.x), fmaxf(fmaxf(p0.y, p1.y), p2.y), fmaxf(fmaxf(p0.z, p1.z), p2.z), 0.f);
+    if (fabsf(hi.x - lo.x) < 0.001f) { lo.x -= 0.001f; hi.x += 0.001f; }
+    if (fabsf(hi.y - lo.y) < 0.001f) { lo.y -= 0.001f; hi.y += 0.001f; }
+    if (fabsf(hi.z - lo.z) < 0.001f) { lo.z -= 0.001f; hi.z += 0.001f; }
+}
+// The reference's gating rule, exact (round 4).  bvh.rs:115-151 tests an item iff the ray passes the box of every node down to the
+// item's LEAF NODE — i.e. iff it passes that node's box (a DoubleLeaf's is the union of its two items'; the ancestors' are supersets
+// and the slab arithmetic is monotone).  The walked trees hold the items' own boxes, relaxed (hit_aabb_entry), so a hit that is about
+// to become its ray's best is put to the rule itself, with the reference's own test (hit_aabb, the caller's [tmin, tmax]):
+//   triangle: its own box (recomputed from the vertices: no fetch) is inside its leaf node's, so passing it suffices; otherwise the
+//             leaf node's box decides (tri_gate, 32 B from HBM: one hit in ~1e7);
+//   object:   its reference leaf-node box (obj_gate), fetched with the object record.
+__device__ __forceinline__ bool tri_gate_ok(const DScene &sc, size_t tri, V3 p0, V3 p1, V3 p2, V3 o, V3 inv, float tmin, float tmax) {
+    float4 lo, hi;
+    triangle_box(p0, p1, p2, lo, hi);
+    if (hit_aabb(lo, hi, o, inv, tmin, tmax)) return true;
+    return hit_aabb(sc.tri_gate[2 * tri], sc.tri_gate[2 * tri + 1], o, inv, tmin, tmax);
+}
+__device__ __forceinline__ bool obj_gate_ok(const DScene &sc, uint32_t k, V3 o, V3 inv) {
+    return hit_aabb(sc.obj_gate[2 * (size_t)k], sc.obj_gate[2 * (size_t)k + 1], o, inv, 0.001f, 2e9f);      // render.rs:19: the walk's [t_min, t_max]
 }
 // Per-lane traversal stack in LDS, laid out [level][lane] so a push/pop by the whole wave touches
 // 64 consecutive dwords (conflict-free).  `base` = first level this traversal may use.
@@ -672,16 +745,16 @@ struct LdsStack16 {
 // decides two boxes; with one box per node every box test waited for its own dependent fetch and the walk was
 // latency-bound).  Returns the next reference: the nearer hit child (the farther one is pushed), else a popped one.
 // A child is entered when the reference's own test passes (aabb.rs:30-50 with the caller's [tmin, tmax]) and its entry
-// is not clearly beyond the best hit so far: `cull` = cull_bound(best t) = best t + 1e-6 |best t|.  The slack covers the few ulp by which a
+// is not clearly beyond the best hit so far: `cull` = cull_bound(best t) = best t + 2^-10 |best t|.  The slack covers what a
 // computed slab entry can exceed the t of a hit lying on the box face, and keeps exact ties (which the in-order rank
 // decides) reachable — so the result does not depend on the shape of the walked tree.
 template <class Stack>
-__device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, uint32_t node, V3 o, V3 inv, float tmin, float tmax,
+__device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, uint32_t node, V3 o, V3 inv, V3 inv_hi, float tmin, float tmax,
                                               float cull, Stack &st) {
     const float4 *nd = nodes + 4 * (size_t)node;
     const float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
     float tl, tr;
-    bool hl = hit_aabb_entry(q0, q1, o, inv, tmin, tmax, tl), hr = hit_aabb_entry(q2, q3, o, inv, tmin, tmax, tr);
+    bool hl = hit_aabb_entry(q0, q1, o, inv, inv_hi, tmin, tmax, tl), hr = hit_aabb_entry(q2, q3, o, inv, inv_hi, tmin, tmax, tr);
     hl = hl && !(tl > cull); hr = hr && !(tr > cull);
     const uint32_t rl = __float_as_uint(q0.w), rr = __float_as_uint(q1.w);
     // Flat, not nested: one predicated push and one predicated pop around a select.  The nested form (both -> push and return,
@@ -710,7 +783,11 @@ __device__ __forceinline__ uint32_t pair_step(const float4 *__restrict__ nodes, 
 #ifdef FW_NO_CULL     // A/B build (tools/diverge.py): no culling against the best hit, every box test is the reference's alone
 __device__ __forceinline__ float cull_bound(float) { return 3.40282347e+38f; }
 #else
-__device__ __forceinline__ float cull_bound(float t) { return t + fabsf(t) * 1e-6f; }
+// Round 4: the slack is 2^-10 of t (it was 1e-6).  A quadratic's root at the silhouette of a sphere, cone or cylinder carries the
+// square root of its discriminant's rounding: up to 2^-11.5 of the distance, whatever the radius — such a hit can precede the entry
+// of its own box by that much, and the reference, which never culls, takes it (part2 pixel 845940, sample 176: two spheres of the
+// cluster 1.2e-5 apart in t, gpurun_out/r04d).  Boxes entered up to 0.1 % beyond the best hit cost nothing measurable.
+__device__ __forceinline__ float cull_bound(float t) { return t + fabsf(t) * (1.0f / 1024.0f); }
 #endif
 
 // K4  mesh BLAS (bvh.rs:100-151 over Triangle items).  The reference visits BOTH children with the caller's
@@ -726,6 +803,7 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
     const TriRay tr = make_triray(r);
     LdsStack st{stack_base, 0};
     bool have = false; float best = tmax; uint32_t best_tri = 0;
+    const bool soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);               // the SOFT class: walked without culling
     uint32_t cur = root;                                                 // a reference: pair node, REF_LEAF | triangle, or REF_DONE
     while (cur != REF_DONE) {
         // while-while: every lane first walks pair nodes until it holds a leaf (or runs out of tree); only then do the
@@ -733,7 +811,7 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
         while (!(cur & REF_LEAF)) {
             TS_TICK(4);
             // cull_t: a t the caller already holds from another object (hits beyond it cannot win; equal t still can)
-            cur = pair_step(sc.blas, cur, r.o, inv, tmin, tmax, cull_bound(have ? fminf(best, cull_t) : cull_t), st);
+            cur = pair_step(sc.blas, cur, r.o, inv, relaxed(inv), tmin, tmax, soft ? NO_CULL : cull_bound(have ? fminf(best, cull_t) : cull_t), st);
         }
         if (cur == REF_DONE) break;
         const uint32_t item = cur & NODE_MASK;
@@ -744,7 +822,8 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
         float t, b0, b1, b2;
         if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, tmin, tmax, t, b0, b1, b2)) {
             // tie -> the item that comes later in the reference tree's in-order (ranks fetched only then)
-            if (!have || t < best || (t == best && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + best_tri])) { have = true; best = t; best_tri = item; }
+            if ((!have || t < best || (t == best && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + best_tri])) &&
+                tri_gate_ok(sc, tri_base + item, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), r.o, inv, tmin, tmax)) { have = true; best = t; best_tri = item; }
         }
     }
     t_out = best; tri_out = best_tri;
@@ -958,7 +1037,7 @@ constexpr uint32_t BLAS_RUN_MIN = FW_BLAS_RUN_MIN;     // parked rays that start
 #define FW_TLAS_REFILL_MIN 16
 #endif
 #ifndef FW_TLAS_WAVES
-#define FW_TLAS_WAVES 5
+#define FW_TLAS_WAVES 4      // round 4: the gate check (obj_gate_ok) and the relaxed exit planes took the refilling L2 walks past the 96 registers of 5 waves (24-36 spills)
 #endif
 #ifndef FW_BLAS_WAVES
 #define FW_BLAS_WAVES 5
@@ -1054,7 +1133,7 @@ struct BlockStream {
 };
 // The objects the host kept out of the walked TLAS (DScene.hoisted: boxes that cover most of the scene, met by nearly every
 // ray): tested here for one ray with wave-uniform object indices — scalar loads, no divergence between lanes — exactly as
-// their leaf would: the object's own box first (obj_cull = its leaf box in the walked tree), the gate box where it has one,
+// their leaf would: the object's leaf box first (obj_leaf = its box in the walked tree: that of its reference leaf node), the gate box where it has one,
 // then the object with the caller's [TMIN, TMAX], ties by reference rank.  A walk that starts from this result culls
 // against its t like against any other hit.
 __device__ __forceinline__ void hoisted_hits(const DScene &sc, const Ray &r, V3 inv, const RngKey &key, int segment, uint32_t *blas_stack,
@@ -1062,12 +1141,12 @@ __device__ __forceinline__ void hoisted_hits(const DScene &sc, const Ray &r, V3 
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     for (uint32_t h = 0; h < sc.n_hoisted; h++) {
         const uint32_t k = sc.hoisted[h];
-        if (!hit_aabb(sc.obj_cull[2 * (size_t)k], sc.obj_cull[2 * (size_t)k + 1], r.o, inv, TMIN, TMAX)) continue;
+        float entry;
+        if (!hit_aabb_entry(sc.obj_leaf[2 * (size_t)k], sc.obj_leaf[2 * (size_t)k + 1], r.o, inv, relaxed(inv), TMIN, TMAX, entry)) continue;
         Obj o = load_obj(sc.obj, k);
-        if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)k], sc.obj_gate[2 * (size_t)k + 1], r.o, inv, TMIN, TMAX)) continue;
         float t; uint32_t prim;
         if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
-            if (!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = k; best_prim = prim; }
+            if ((!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, k, r.o, inv)) { have = true; best_t = t; best_obj = k; best_prim = prim; }
         }
     }
 }
@@ -1077,7 +1156,7 @@ __device__ __forceinline__ void hoisted_hits(const DScene &sc, const Ray &r, V3 
 template <bool USE_BVH, bool DEFER>
 __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, const RngKey &key, int segment,
                                             uint32_t *my_stack, uint32_t *blas_stack, float &best_t, uint32_t &best_obj,
-                                            uint32_t &best_prim, bool &deferred, uint32_t &deferred_obj) {
+                                            uint32_t &best_prim, bool &deferred, uint32_t &deferred_obj, bool soft = false) {
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     if (!USE_BVH) {
         // scene.rs:137-149: linear scan with narrowing; a later object replaces on t <= closest
@@ -1142,19 +1221,21 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
                 if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;   // n_walk < n_busy: somebody holds a leaf or has finished
                 if (walking) {
                     TS_TICK(0);
-                    cur = pair_step(sc.tlas, cur, r.o, inv, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
+                    cur = pair_step(sc.tlas, cur, r.o, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? best_t : TMAX), st);
                 }
             }
             if (!busy || !(cur & REF_LEAF) || cur == REF_DONE) continue;
             const uint32_t item = cur & NODE_MASK;
             cur = st.sp ? st.pop() : REF_DONE;
             Obj o = load_obj_for_hit(sc.obj, item);
-            if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)item], sc.obj_gate[2 * (size_t)item + 1], r.o, inv, TMIN, TMAX)) continue;
-            if (DEFER && sc.has_mesh && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = item; continue; }   // park the first mesh
+            if (DEFER && sc.has_mesh && obj_kind(o) == 5u && !deferred) {                  // park the first mesh — if the reference's walk reaches it (obj_gate_ok)
+                if (obj_gate_ok(sc, item, r.o, inv)) { deferred = true; deferred_obj = item; }
+                continue;
+            }
             TS_TICK(2);
             float t; uint32_t prim;
             if (hit_object(sc, o, item, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
-                if (!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = item; best_prim = prim; }
+                if ((!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, item, r.o, inv)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
             }
         }
     }
@@ -1187,6 +1268,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
         uint32_t slot = 0, obj = 0, tri_base = 0, bobj = MISS, bprim = 0, mtri = 0, cur = REF_DONE;
         float bt = TMAX, mbest = TMAX;
         V3 ro = mk(0, 0, 0), inv = ro;
+        bool soft = false;
         TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
         LdsStack st{blas_stack, 0};
         for (;;) {
@@ -1202,6 +1284,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                     Obj o = load_obj(sc.obj, obj);
                     Ray r = to_object_space(o, make_ray(ra, rb, f, segment));
                     ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                    soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
                     tr = make_triray(r);
                     tri_base = o.aux1; cur = o.aux0; st.sp = 0;
                     have = false; mbest = TMAX; mtri = 0; act = true;
@@ -1220,7 +1303,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                 if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;   // n_walk < n_act: somebody holds a leaf, the round makes progress
                 if (walking) {
                     TS_TICK(4);
-                    cur = pair_step(sc.blas, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
+                    cur = pair_step(sc.blas, cur, ro, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
                 }
             }
             if (act && (cur & REF_LEAF)) {
@@ -1232,7 +1315,8 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                     float4 a = tp[0], b = tp[1], c = tp[2];
                     float t, b0, b1, b2;
                     if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, TMIN, TMAX, t, b0, b1, b2)) {
-                        if (!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) { have = true; mbest = t; mtri = item; }
+                        if ((!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) &&
+                        tri_gate_ok(sc, tri_base + item, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, inv, TMIN, TMAX)) { have = true; mbest = t; mtri = item; }
                     }
                 }
                 if (cur == REF_DONE) {                                  // this ray is finished: merge with what the TLAS walk held
@@ -1254,13 +1338,14 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
         float4 ca = make_float4(0, 0, 0, 0), na = ca; float2 cb = make_float2(0, 0), nb = cb; float cs = 0.f, ns = 0.f;
         uint32_t cur_base = 0, q_next = 0;
         auto fetch = [&](uint32_t j, float4 &a, float2 &b, float &st) {
-            if (j < n) { a = qld(&in.ray_a[base + j]); b = load_ray_b(in, base + j, f, segment); if (sc.has_medium) st = load_state(in, base + j, segment).w; }
+            if (j < n) { a = qld(&in.ray_a[base + j]); b = load_ray_b(in, base + j, f, segment); if (sc.has_medium) st = load_home(in, base + j, f, segment); }
         };
         fetch(lane, ca, cb, cs); fetch(64u + lane, na, nb, ns);
         const uint32_t IDLE = 0xffffffffu;
         uint32_t slot = IDLE, cur = REF_DONE, path_id = 0, best_obj = MISS, best_prim = 0, deferred_obj = 0;
         float best_t = TMAX; bool have = false, deferred = false;
         V3 wo = mk(0, 0, 0), wd = wo, inv = wo;
+        bool soft = false;                                              // the SOFT class (scenes with meshes): no culling
         LdsStack st{my_stack, 0};
         uint32_t park_n = 0;                                            // rays handed over to k_blas so far (wave-uniform)
         for (;;) {
@@ -1285,6 +1370,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                         const Ray r = make_ray(ra, rb, f, segment);
                         wo = r.o; wd = r.d;
                         inv = mk(fdiv(1.f, wd.x), fdiv(1.f, wd.y), fdiv(1.f, wd.z));
+                        soft = PARK && soft_ray(f.ex, wd, sc.soft_shear);
                         path_id = __float_as_uint(rs);
                         cur = skip_ray(f.ex, r) ? REF_DONE : sc.tlas_root; st.sp = 0;      // a NaN ray's record comes from k_extend_exact
                         have = false; best_t = TMAX; best_obj = MISS; best_prim = 0; deferred = false; deferred_obj = 0;
@@ -1313,24 +1399,22 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                 if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
                 if (walking) {
                     TS_TICK(0);
-                    cur = pair_step(sc.tlas, cur, wo, inv, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
+                    cur = pair_step(sc.tlas, cur, wo, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? best_t : TMAX), st);
                 }
             }
             if (busy && (cur & REF_LEAF) && cur != REF_DONE) {
                 const uint32_t item = cur & NODE_MASK;
                 cur = st.sp ? st.pop() : REF_DONE;
                 Obj o = load_obj_for_hit(sc.obj, item);
-                const bool gated_out = (obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)item], sc.obj_gate[2 * (size_t)item + 1], wo, inv, TMIN, TMAX);
-                if (!gated_out) {
-                    if (PARK && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = item; }   // the first mesh: this ray goes to k_blas
-                    else {
-                        TS_TICK(2);
-                        RngKey key{0, 0, 0};
-                        if (sc.has_medium) key = key_of(f, path_id);
-                        float t; uint32_t prim;
-                        if (hit_object(sc, o, item, Ray{wo, wd}, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
-                            if (!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = item; best_prim = prim; }
-                        }
+                if (PARK && obj_kind(o) == 5u && !deferred) {            // the first mesh: this ray goes to k_blas — if the reference's walk reaches the mesh (obj_gate_ok)
+                    if (obj_gate_ok(sc, item, wo, inv)) { deferred = true; deferred_obj = item; }
+                } else {
+                    TS_TICK(2);
+                    RngKey key{0, 0, 0};
+                    if (sc.has_medium) key = key_of(f, path_id);
+                    float t; uint32_t prim;
+                    if (hit_object(sc, o, item, Ray{wo, wd}, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+                        if ((!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, item, wo, inv)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
                     }
                 }
             }
@@ -1372,9 +1456,10 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
         if (active) {
             Ray r = make_ray(ra, rb, f, segment);
             RngKey key{0, 0, 0};
-            if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
+            if (sc.has_medium) key = key_of(f, __float_as_uint(load_home(in, i, f, segment)));
             if (!skip_ray(f.ex, r))     // a NaN ray's record comes from k_extend_exact
-                closest_hit<USE_BVH, USE_BVH>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj);
+                closest_hit<USE_BVH, USE_BVH>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj,
+                                              USE_BVH && sc.has_mesh && soft_ray(f.ex, r.d, sc.soft_shear));
             if (!USE_BVH && f.hit4) reinterpret_cast<uint32_t *>(hits)[i] = __float_as_uint(pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y);   // the code alone: k_shade recomputes t
             else if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
         }
@@ -1436,19 +1521,22 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVE
         if (active) {
             r = make_ray(ra, rb, f, segment);
             RngKey key{0, 0, 0};
-            if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, i, segment).w));
+            if (sc.has_medium) key = key_of(f, __float_as_uint(load_home(in, i, f, segment)));
             const V3 inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+            const bool soft = sc.has_mesh && soft_ray(f.ex, r.d, sc.soft_shear);              // no culling against a t that may be rounding noise
             const uint32_t n_obj = skip_ray(f.ex, r) ? 0u : sc.n_objects;      // a NaN ray's record comes from k_extend_exact
             for (uint32_t k = 0; k < n_obj; k++) {
-                const float4 lo = sc.obj_cull[2 * (size_t)k], hi = sc.obj_cull[2 * (size_t)k + 1];   // the leaf's box in the walked tree
+                const float4 lo = sc.obj_leaf[2 * (size_t)k], hi = sc.obj_leaf[2 * (size_t)k + 1];   // the leaf's box in the walked tree
                 float entry;
-                if (!hit_aabb_entry(lo, hi, r.o, inv, TMIN, TMAX, entry) || entry > cull_bound(have ? best_t : TMAX)) continue;
+                if (!hit_aabb_entry(lo, hi, r.o, inv, relaxed(inv), TMIN, TMAX, entry) || entry > (soft ? NO_CULL : cull_bound(have ? best_t : TMAX))) continue;
                 Obj o = load_obj(sc.obj, k);
-                if ((obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)k], sc.obj_gate[2 * (size_t)k + 1], r.o, inv, TMIN, TMAX)) continue;
-                if (PARK && obj_kind(o) == 5u && !deferred) { deferred = true; deferred_obj = k; continue; }
+                if (PARK && obj_kind(o) == 5u && !deferred) {                // the first mesh is parked — if the reference's walk reaches it (obj_gate_ok)
+                    if (obj_gate_ok(sc, k, r.o, inv)) { deferred = true; deferred_obj = k; }
+                    continue;
+                }
                 float t; uint32_t prim;
                 if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
-                    if (!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = k; best_prim = prim; }
+                    if ((!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, k, r.o, inv)) { have = true; best_t = t; best_obj = k; best_prim = prim; }
                 }
             }
             if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
@@ -1595,10 +1683,12 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(7, 8)))
 void k_extend_linear(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
     extend_body<false, false, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
 }
+#if FW_AB
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(5, 8)))
 void k_extend_bvh(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
     extend_body<true, false, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
 }
+#endif
 // scenes without meshes: the TLAS walk with in-wave refill (part2 @16 spp: 9.6 vs 10.5 ms)
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_TLAS_WAVES, 8)))
 void k_extend_tlas(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
@@ -1637,6 +1727,7 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
     uint32_t slot = 0, obj = 0, tri_base = 0, bcode = MISS, mtri = 0, cur = REF_DONE;
     float bt = TMAX, mbest = TMAX;
     V3 ro = mk(0, 0, 0), inv = ro;
+    bool soft = false;
     TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
     LdsStack st{lds_stack + threadIdx.x, 0};
     for (;;) {
@@ -1656,6 +1747,7 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
                     Obj o = load_obj(sc.obj, obj);
                     Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
                     ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                    soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
                     tr = make_triray(r);
                     tri_base = o.aux1; cur = o.aux0; st.sp = 0;
                     have = false; mbest = TMAX; mtri = 0; act = true;
@@ -1674,7 +1766,7 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
             if (walking) {
                 TS_TICK(4);
-                cur = pair_step(sc.blas, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
+                cur = pair_step(sc.blas, cur, ro, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
             }
         }
         if (act && (cur & REF_LEAF)) {
@@ -1686,7 +1778,8 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, b0, b1, b2;
                 if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, TMIN, TMAX, t, b0, b1, b2)) {
-                    if (!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) { have = true; mbest = t; mtri = item; }
+                    if ((!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) &&
+                        tri_gate_ok(sc, tri_base + item, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, inv, TMIN, TMAX)) { have = true; mbest = t; mtri = item; }
                 }
             }
             if (cur == REF_DONE) {                                      // finished: merge with what the TLAS walk held
@@ -1764,6 +1857,7 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
     float bt = TMAX, mbest = TMAX;
     uint32_t pend = REF_DONE;                                       // a triangle put aside while its lane walks on (REF_DONE: none)
     V3 ro = mk(0, 0, 0), inv = ro;
+    bool soft = false;
     TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
     LdsStack16 st{stacks + (size_t)wib * levels * 64u + lane, 0};
     for (;;) {
@@ -1783,6 +1877,7 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
                     Obj o = load_obj(sc.obj, obj);
                     Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
                     ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                    soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
                     tr = make_triray(r);
                     tri_base = o.aux1; cur = o.aux0; st.sp = 0;
                     have = false; mbest = TMAX; mtri = 0; act = true;
@@ -1805,10 +1900,10 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
             const bool walking = act && !(cur & REF_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
-            if (walking) cur = pair_step(lds_nodes, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
+            if (walking) cur = pair_step(lds_nodes, cur, ro, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
             // two steps per exit check: the ballot, the count and the exit rule cost a third of a step's issue time
             // (suzanne @64 10.1 -> 9.9 ms; the TLAS walk of part2 gains nothing from the same and keeps one)
-            if (act && !(cur & REF_LEAF)) cur = pair_step(lds_nodes, cur, ro, inv, TMIN, TMAX, cull_bound(have ? fminf(mbest, bt) : bt), st);
+            if (act && !(cur & REF_LEAF)) cur = pair_step(lds_nodes, cur, ro, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
         }
         for (int pass = 0; pass < 2; pass++) {                         // the triangles put aside, then the ones held
             uint32_t item = REF_DONE;
@@ -1820,7 +1915,8 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, b0, b1, b2;
                 if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, TMIN, TMAX, t, b0, b1, b2)) {
-                    if (!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) { have = true; mbest = t; mtri = item; }
+                    if ((!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) &&
+                        tri_gate_ok(sc, tri_base + item, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, inv, TMIN, TMAX)) { have = true; mbest = t; mtri = item; }
                 }
             }
         }
@@ -1859,7 +1955,7 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     float4 ca = make_float4(0, 0, 0, 0), na = ca; float2 cb = make_float2(0, 0), nb = cb; float cs = 0.f, ns = 0.f;
     auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float &st) {
-        if (lane < b_n) { a = qld(&in.ray_a[b_base + lane]); b = load_ray_b(in, b_base + lane, f, segment); if (sc.has_medium) st = load_state(in, b_base + lane, segment).w; }
+        if (lane < b_n) { a = qld(&in.ray_a[b_base + lane]); b = load_ray_b(in, b_base + lane, f, segment); if (sc.has_medium) st = load_home(in, b_base + lane, f, segment); }
     };
     uint32_t c_n = 0, c_pos = 0, c_base = 0, n_n = 0, n_base = 0;
     if (bs.next(c_base, c_n)) fetch(c_base, c_n, ca, cb, cs); else c_n = 0;
@@ -1930,23 +2026,305 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
             const bool walking = busy && !(cur & REF_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
-            if (walking) cur = pair_step(lds_nodes, cur, wo, inv, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
+            if (walking) cur = pair_step(lds_nodes, cur, wo, inv, relaxed(inv), TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
         }
         if (busy && (cur & REF_LEAF) && cur != REF_DONE) {
             const uint32_t item = cur & NODE_MASK;
             cur = st.sp ? st.pop() : REF_DONE;
             Obj o = load_obj_for_hit(sc.obj, item);
-            const bool gated_out = (obj_flags(o) & OF_GATE) && !hit_aabb(sc.obj_gate[2 * (size_t)item], sc.obj_gate[2 * (size_t)item + 1], wo, inv, TMIN, TMAX);
-            if (!gated_out) {
-                RngKey key{0, 0, 0};
-                if (sc.has_medium) key = key_of(f, path_id);
-                float t; uint32_t prim;
-                if (hit_object(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)) {   // no meshes in these scenes: no BLAS stack
-                    if (!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) { have = true; best_t = t; best_obj = item; best_prim = prim; }
-                }
+            RngKey key{0, 0, 0};
+            if (sc.has_medium) key = key_of(f, path_id);
+            float t; uint32_t prim;
+            if (hit_object(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)) {   // no meshes in these scenes: no BLAS stack
+                if ((!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, item, wo, inv)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
             }
         }
         const bool done = slot != IDLE && cur == REF_DONE;
+        if (done) { qst(&hits[slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits)); slot = IDLE; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// WIDE walks (round 4): k_blas_wide / k_extend_tlas_wide = k_blas_lds / k_extend_tlas_lds over WIDE nodes (fw_device.h): four
+// children per node.  Why: the pair walks issue vector instructions 70 % of the time with half their lanes (profiles/r03z_*_sq.json),
+// and a third of what a wave issues per step is not box arithmetic — the stack operation, the ballots and exit rule of the round,
+// the scalar bookkeeping of the loop.  A wide step decides four boxes for one of each, and the tree has a third of the pair tree's
+// nodes: suzanne's BLAS 62 KB -> 36 KB as f32 nodes, part2's TLAS 90 -> 53 KB; teapot.yml's four meshes (404 KB of pair nodes: the
+// L2 walk until now) are 101 KB as quantised nodes and walk out of LDS for the first time.
+//   WIDE_F32: the children's own boxes, the slab test of aabb.rs:30-50 on them: an item is reached iff its own box passes and its
+//             entry is not beyond the culling bound — the pair walk's decisions, bit for bit.
+//   WIDE_Q8 : boxes rounded outward to 8 bits (a superset under the same monotone arithmetic): they only cull; an item reached
+//             through one is tested like any other, ties go by reference rank, rays whose result depends on HOW the trees are
+//             walked are on the exact list either way.
+// The near / far planes are chosen by the ray's signs BEFORE the arithmetic (one offset per axis kept per ray), so a box costs
+// 6 subtractions, 6 multiplications, max3 / min3 and two comparisons.  The children that pass are ordered by a 5-comparator
+// network on 32-bit keys (upper half of the entry distance | reference): nearest next, the others pushed farthest first.
+// ------------------------------------------------------------------------------------------------
+struct LdsStackW {   // 16-bit references, [level][lane] over the 64 lanes of one wave
+    uint16_t *s; int sp;
+    __device__ __forceinline__ void push(uint32_t v) { s[sp * 64] = (uint16_t)v; sp++; }
+    __device__ __forceinline__ uint32_t pop() { sp--; return s[sp * 64]; }
+};
+// per ray: WIDE_F32 byte offsets (inside a node) of the near planes of x, y, z and of the far planes; WIDE_Q8: q[0..2] = inv < 0
+struct WideSel { uint32_t q[6]; };
+template <int FMT> __device__ __forceinline__ WideSel wide_sel(V3 inv) {
+    WideSel s;
+    const bool nx = inv.x < 0.f, ny = inv.y < 0.f, nz = inv.z < 0.f;       // the selection of aabb.rs:36-38 (`if inv_d < 0 { swap }`)
+    if (FMT == WIDE_F32) { s.q[0] = nx ? 48u : 0u; s.q[1] = ny ? 64u : 16u; s.q[2] = nz ? 80u : 32u; s.q[3] = nx ? 0u : 48u; s.q[4] = ny ? 16u : 64u; s.q[5] = nz ? 32u : 80u; }
+    else { s.q[0] = nx ? 1u : 0u; s.q[1] = ny ? 1u : 0u; s.q[2] = nz ? 1u : 0u; s.q[3] = s.q[4] = s.q[5] = 0u; }
+    return s;
+}
+template <int FMT>
+__device__ __forceinline__ uint32_t wide_step(const uint32_t *__restrict__ nodes, uint32_t node, V3 o, V3 inv, V3 inv_hi, const WideSel &sel,
+                                              float tmin, float tmax, float cull, LdsStackW &st) {
+    float4 NX, NY, NZ, FX, FY, FZ; uint32_t r01, r23;
+    if (FMT == WIDE_F32) {
+        const char *nd = reinterpret_cast<const char *>(nodes) + __umul24(node, WIDE_F32_DW * 4u);     // node < 2^15: the 24-bit multiply is full rate
+        NX = *reinterpret_cast<const float4 *>(nd + sel.q[0]); NY = *reinterpret_cast<const float4 *>(nd + sel.q[1]); NZ = *reinterpret_cast<const float4 *>(nd + sel.q[2]);
+        FX = *reinterpret_cast<const float4 *>(nd + sel.q[3]); FY = *reinterpret_cast<const float4 *>(nd + sel.q[4]); FZ = *reinterpret_cast<const float4 *>(nd + sel.q[5]);
+        const uint2 rr = *reinterpret_cast<const uint2 *>(nd + 96);
+        r01 = rr.x; r23 = rr.y;
+    } else {
+        const uint4 *nd = reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(nodes) + __umul24(node, WIDE_Q8_DW * 4u));
+        const uint4 a = nd[0], lo = nd[1], hi = nd[2];
+        const float ox = __uint_as_float(a.x), oy = __uint_as_float(a.y), oz = __uint_as_float(a.z);
+        const float sx = __uint_as_float((a.w & 0xffu) << 23), sy = __uint_as_float(((a.w >> 8) & 0xffu) << 23), sz = __uint_as_float(((a.w >> 16) & 0xffu) << 23);
+        const uint32_t nxw = sel.q[0] ? hi.x : lo.x, fxw = sel.q[0] ? lo.x : hi.x, nyw = sel.q[1] ? hi.y : lo.y, fyw = sel.q[1] ? lo.y : hi.y,
+                       nzw = sel.q[2] ? hi.z : lo.z, fzw = sel.q[2] ? lo.z : hi.z;
+        // plane = fma(q, 2^e, origin): q * 2^e is exact, so this is the one rounding the host checked its outward rounding with
+        auto dq = [](uint32_t w, float s, float org) {
+            return make_float4(fmaf((float)(w & 0xffu), s, org), fmaf((float)((w >> 8) & 0xffu), s, org), fmaf((float)((w >> 16) & 0xffu), s, org), fmaf((float)(w >> 24), s, org));
+        };
+        NX = dq(nxw, sx, ox); NY = dq(nyw, sy, oy); NZ = dq(nzw, sz, oz); FX = dq(fxw, sx, ox); FY = dq(fyw, sy, oy); FZ = dq(fzw, sz, oz);
+        r01 = lo.w; r23 = hi.w;
+    }
+    const uint32_t NONE = 0xffffffffu;
+    // hit_aabb_entry on one child with the planes already chosen; entry clamped to tmin (> 0 here: the bits of a positive float order
+    // like unsigned integers).  key = upper half of the entry | reference; a child that fails gets NONE, which sorts last and whose
+    // low half reads W_DONE.
+    auto key = [&](float nx, float ny, float nz, float fx, float fy, float fz, uint32_t ref16) -> uint32_t {
+        const float tn = fmaxf(fmaxf(fmaxf((nx - o.x) * inv.x, (ny - o.y) * inv.y), (nz - o.z) * inv.z), tmin);
+        const float tf = fminf(fminf(fminf((fx - o.x) * inv_hi.x, (fy - o.y) * inv_hi.y), (fz - o.z) * inv_hi.z), tmax);   // relaxed exit (hit_aabb_entry)
+        const bool hit = tf > tn && !(tn > cull);
+        return hit ? ((__float_as_uint(tn) & 0xffff0000u) | ref16) : NONE;
+    };
+    const uint32_t k0 = key(NX.x, NY.x, NZ.x, FX.x, FY.x, FZ.x, r01 & 0xffffu), k1 = key(NX.y, NY.y, NZ.y, FX.y, FY.y, FZ.y, r01 >> 16),
+                   k2 = key(NX.z, NY.z, NZ.z, FX.z, FY.z, FZ.z, r23 & 0xffffu), k3 = key(NX.w, NY.w, NZ.w, FX.w, FY.w, FZ.w, r23 >> 16);
+    const uint32_t a = min(k0, k1), b = max(k0, k1), c = min(k2, k3), d = max(k2, k3);
+    const uint32_t s0 = min(a, c), m1 = max(a, c), m2 = min(b, d), s3 = max(b, d), s1 = min(m1, m2), s2 = max(m1, m2);
+    // nearest next, the others pushed farthest first (sorted: a valid s3 implies valid s2 and s1)
+    if (s1 != NONE) { if (s2 != NONE) { if (s3 != NONE) st.push(s3); st.push(s2); } st.push(s1); }
+    uint32_t next = s0 & 0xffffu;
+    if (s0 == NONE && st.sp) next = st.pop();
+    return next;
+}
+// workgroup-wide copy of `dwords` (a multiple of 4) dwords into LDS
+__device__ __forceinline__ void stage_lds(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t dwords) {
+    for (uint32_t k = threadIdx.x; k < dwords / 4u; k += blockDim.x) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
+}
+constexpr int WIDE_MAX_WAVES = 16;
+// Dynamic LDS: [wide nodes][triangles (LDS_TRIS)][stacks: waves x levels x 64 u16][counter, 4 dwords][this workgroup's queue counts]
+template <int FMT, bool LDS_TRIS>
+__global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_blas_wide(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q,
+                                                                   uint32_t n_nodes, uint32_t n_tris, uint32_t levels) {
+    extern __shared__ uint32_t lds_w[];
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6, n_waves_wg = blockDim.x >> 6;
+    const uint32_t node_dw = n_nodes * (FMT == WIDE_F32 ? WIDE_F32_DW : WIDE_Q8_DW);
+    stage_lds(lds_w, sc.wblas, node_dw);
+    float4 *lds_tris = reinterpret_cast<float4 *>(lds_w + node_dw);
+    if (LDS_TRIS) stage_lds(reinterpret_cast<uint32_t *>(lds_tris), reinterpret_cast<const uint32_t *>(sc.tri), n_tris * 12u);
+    uint16_t *stacks = reinterpret_cast<uint16_t *>(lds_tris + (LDS_TRIS ? (size_t)n_tris * 3u : 0u));
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(stacks + (size_t)n_waves_wg * levels * 64u);
+    const uint32_t n_k = (q.n_waves + gridDim.x - 1u - blockIdx.x) / gridDim.x;      // this workgroup's queues: blockIdx.x + k * gridDim.x (k_blas_lds)
+    uint32_t *lds_cnt = ctr + 4;
+    for (uint32_t k = threadIdx.x; k < n_k; k += blockDim.x) lds_cnt[k] = park.pcount[blockIdx.x + k * gridDim.x];
+    if (threadIdx.x == 0) *ctr = 0u;
+    __syncthreads();
+    BlockStream bs;
+    bs.init(park.pcount, 0u, 0u, park.stride, lane, blockIdx.x, gridDim.x);
+    bs.init_units(ctr, n_k, lds_unit(park.stride), lds_cnt);
+    bs.ptotal = park.ptotal;
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    float4 ca = make_float4(0, 0, 0, 0), na = ca, cm = ca, nm = ca; float2 cb = make_float2(0, 0), nb = cb;
+    auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float4 &m) {
+        if (lane < b_n) { a = qld(&park.ray_a[b_base + lane]); b = qld(&park.ray_b[b_base + lane]); m = qld(&park.meta[b_base + lane]); }
+    };
+    uint32_t c_n = 0, c_pos = 0, n_n = 0, bb = 0;
+    if (bs.next(bb, c_n)) fetch(bb, c_n, ca, cb, cm); else c_n = 0;
+    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+    bool act = false, have = false;
+    uint32_t slot = 0, obj = 0, tri_base = 0, bcode = MISS, mtri = 0, cur = W_DONE, pend = W_DONE;
+    float bt = TMAX, mbest = TMAX;
+    V3 ro = mk(0, 0, 0), inv = ro;
+    bool soft = false;
+    WideSel sel = wide_sel<FMT>(inv);
+    TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
+    LdsStackW st{stacks + (size_t)wib * levels * 64u + lane, 0};
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(!act);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (c_pos < c_n) {
+            if (n_idle >= BLAS_REFILL_MIN) {
+                const uint32_t take = min(n_idle, c_n - c_pos);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                const int bsel = (int)(((c_pos + rank) & 63u) << 2);
+                auto bp = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(bsel, __float_as_int(v))); };
+                const float4 ra = make_float4(bp(ca.x), bp(ca.y), bp(ca.z), bp(ca.w));
+                const float2 rb = make_float2(bp(cb.x), bp(cb.y));
+                const float4 me = make_float4(bp(cm.x), bp(cm.y), bp(cm.z), bp(cm.w));
+                if (!act && rank < take) {
+                    slot = __float_as_uint(me.x); obj = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
+                    Obj o = load_obj(sc.obj, obj);
+                    Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
+                    ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+                    sel = wide_sel<FMT>(inv);
+                    soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
+                    tr = make_triray(r);
+                    tri_base = o.aux1; cur = sc.obj_wroot[obj]; st.sp = 0;
+                    have = false; mbest = TMAX; mtri = 0; act = true;
+                }
+                c_pos += take;
+                if (c_pos == c_n) {
+                    ca = na; cb = nb; cm = nm; c_n = n_n; c_pos = 0;
+                    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+                }
+            }
+        } else if (n_idle == 64u) break;
+
+        const uint32_t n_act = (uint32_t)__popcll(__ballot(act));
+        for (;;) {
+            // a triangle put aside while its lane walks on (k_blas_lds: one at most; same tests, same winner)
+            if (act && (cur & W_LEAF) && cur != W_DONE && pend == W_DONE && st.sp > 0) { pend = cur; cur = st.pop(); }
+            const bool walking = act && !(cur & W_LEAF);
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+            if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
+            if (walking) cur = wide_step<FMT>(lds_w, cur, ro, inv, relaxed(inv), sel, TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+        }
+        for (int pass = 0; pass < 2; pass++) {                         // the triangles put aside, then the ones held
+            uint32_t item = W_DONE;
+            if (pass == 0) { if (act && pend != W_DONE) { item = pend & 0x7fffu; pend = W_DONE; } }
+            else if (act && (cur & W_LEAF) && cur != W_DONE) { item = cur & 0x7fffu; cur = st.sp ? st.pop() : W_DONE; }
+            if (__ballot(item != W_DONE) == 0ull) continue;
+            if (item != W_DONE) {
+                const float4 *tp = (LDS_TRIS ? lds_tris : sc.tri) + 3 * (size_t)(tri_base + item);
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, b0, b1, b2;
+                if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, TMIN, TMAX, t, b0, b1, b2)) {
+                    if ((!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) &&
+                        tri_gate_ok(sc, tri_base + item, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, inv, TMIN, TMAX)) { have = true; mbest = t; mtri = item; }
+                }
+            }
+        }
+        if (act && cur == W_DONE) {
+            const uint32_t bobj = bcode == MISS ? MISS : (bcode >> sc.prim_bits);
+            if (have && (bobj == MISS || mbest < bt || (mbest == bt && sc.obj_rank[obj] > sc.obj_rank[bobj]))) { bt = mbest; bcode = (obj << sc.prim_bits) | mtri; }
+            qst(&hits[slot], make_float2(bt, __uint_as_float(bcode)));
+            act = false;
+        }
+    }
+}
+
+// k_extend_tlas_lds over WIDE_F32 nodes (scenes without meshes: part2's TLAS, random_spheres)
+__global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q,
+                                                                          int segment, uint32_t n_nodes, uint32_t levels) {
+    extern __shared__ uint32_t lds_w[];
+    const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6, n_waves_wg = blockDim.x >> 6;
+    const uint32_t node_dw = n_nodes * WIDE_F32_DW;
+    stage_lds(lds_w, sc.wtlas, node_dw);
+    uint16_t *stacks = reinterpret_cast<uint16_t *>(lds_w + node_dw);
+    uint32_t *ctr = reinterpret_cast<uint32_t *>(stacks + (size_t)n_waves_wg * levels * 64u);
+    const uint32_t n_k = (q.n_waves + gridDim.x - 1u - blockIdx.x) / gridDim.x;
+    uint32_t *lds_cnt = ctr + 4;
+    for (uint32_t k = threadIdx.x; k < n_k; k += blockDim.x) lds_cnt[k] = q.wcount[(size_t)segment * q.n_waves + blockIdx.x + k * gridDim.x];
+    if (threadIdx.x == 0) *ctr = 0u;
+    __syncthreads();
+    BlockStream bs;
+    bs.init(q.wcount + (size_t)segment * q.n_waves, 0u, 0u, q.cap, lane, blockIdx.x, gridDim.x);
+    bs.init_units(ctr, n_k, lds_unit(q.cap), lds_cnt);
+    const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
+    float4 ca = make_float4(0, 0, 0, 0), na = ca; float2 cb = make_float2(0, 0), nb = cb; float cs = 0.f, ns = 0.f;
+    auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float &st_) {
+        if (lane < b_n) { a = qld(&in.ray_a[b_base + lane]); b = load_ray_b(in, b_base + lane, f, segment); if (sc.has_medium) st_ = load_home(in, b_base + lane, f, segment); }
+    };
+    uint32_t c_n = 0, c_pos = 0, c_base = 0, n_n = 0, n_base = 0;
+    if (bs.next(c_base, c_n)) fetch(c_base, c_n, ca, cb, cs); else c_n = 0;
+    if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
+    // per-block start-up with every lane busy (k_extend_tlas_lds: prep_block): reciprocal direction + the hoisted objects
+    float h_t = TMAX, hix = 0.f, hiy = 0.f, hiz = 0.f; uint32_t h_obj = MISS, h_prim = 0;
+    auto prep_block = [&]() {
+        h_t = TMAX; h_obj = MISS; h_prim = 0;
+        if (lane < c_n) {
+            const Ray r = make_ray(ca, cb, f, segment);
+            const V3 iv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+            hix = iv.x; hiy = iv.y; hiz = iv.z;
+            if (sc.n_hoisted) {
+                RngKey hkey{0, 0, 0};
+                if (sc.has_medium) hkey = key_of(f, __float_as_uint(cs));
+                bool hv = false;
+                hoisted_hits(sc, r, iv, hkey, segment, nullptr, hv, h_t, h_obj, h_prim);
+            }
+        }
+    };
+    prep_block();
+    const uint32_t IDLE = 0xffffffffu;
+    uint32_t slot = IDLE, cur = W_DONE, path_id = 0, best_obj = MISS, best_prim = 0;
+    float best_t = TMAX; bool have = false;
+    V3 wo = mk(0, 0, 0), wd = wo, inv = wo;
+    WideSel sel = wide_sel<WIDE_F32>(inv);
+    LdsStackW st{stacks + (size_t)wib * levels * 64u + lane, 0};
+    for (;;) {
+        const unsigned long long idle_mask = __ballot(slot == IDLE);
+        const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+        if (c_pos < c_n) {
+            if (n_idle >= TLAS_REFILL_MIN) {
+                const uint32_t take = min(n_idle, c_n - c_pos);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle_mask, 0u));
+                const uint32_t src = c_pos + rank;
+                const int bsel = (int)((src & 63u) << 2);
+                auto bp = [&](float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(bsel, __float_as_int(v))); };
+                const float4 ra = make_float4(bp(ca.x), bp(ca.y), bp(ca.z), bp(ca.w));
+                const float2 rb = make_float2(bp(cb.x), bp(cb.y));
+                const float rs = sc.has_medium ? bp(cs) : 0.f;
+                const V3 rinv = mk(bp(hix), bp(hiy), bp(hiz));
+                const float rt = bp(h_t); const uint32_t robj = __float_as_uint(bp(__uint_as_float(h_obj))), rprim = __float_as_uint(bp(__uint_as_float(h_prim)));
+                if (slot == IDLE && rank < take) {
+                    slot = c_base + src;
+                    const Ray r = make_ray(ra, rb, f, segment);
+                    wo = r.o; wd = r.d;
+                    inv = rinv; sel = wide_sel<WIDE_F32>(inv);
+                    path_id = __float_as_uint(rs);
+                    cur = skip_ray(f.ex, r) ? W_DONE : sc.wtlas_root; st.sp = 0;          // a NaN ray's record comes from k_extend_exact
+                    have = robj != MISS; best_t = rt; best_obj = robj; best_prim = rprim;     // what the hoisted objects gave (prep_block)
+                }
+                c_pos += take;
+                if (c_pos == c_n) {
+                    ca = na; cb = nb; cs = ns; c_n = n_n; c_base = n_base; c_pos = 0;
+                    if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
+                    prep_block();
+                }
+            }
+        } else if (n_idle == 64u) break;
+
+        const bool busy = slot != IDLE && cur != W_DONE;
+        const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
+        for (;;) {
+            const bool walking = busy && !(cur & W_LEAF);
+            const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
+            if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
+            if (walking) cur = wide_step<WIDE_F32>(lds_w, cur, wo, inv, relaxed(inv), sel, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
+        }
+        if (busy && (cur & W_LEAF) && cur != W_DONE) {
+            const uint32_t item = cur & 0x7fffu;
+            cur = st.sp ? st.pop() : W_DONE;
+            Obj o = load_obj_for_hit(sc.obj, item);
+            RngKey key{0, 0, 0};
+            if (sc.has_medium) key = key_of(f, path_id);
+            float t; uint32_t prim;
+            if (hit_object(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)) {
+                if ((!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, item, wo, inv)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
+            }
+        }
+        const bool done = slot != IDLE && cur == W_DONE;
         if (done) { qst(&hits[slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits)); slot = IDLE; }
     }
 }
@@ -2357,20 +2735,32 @@ __device__ __forceinline__ bool expensive_shading(const DScene &sc, const float4
     return mkind == 2u || (!(mbits & MF_TEX_CONST) && (mkind == 0u || mkind == 3u || mkind == 4u));
 }
 // CHEAP_ONLY: the caller has sent the expensive cases elsewhere (expensive_shading), their code is compiled out.
-template <bool CHEAP_ONLY = false>
+// CHAIN: the path's state is its chain of material ids (load_state_chain), `chain` in and `nchain` out; beta / nbeta are unused.
+template <bool CHEAP_ONLY = false, bool CHAIN = false>
 __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, const float4 *objp, const float4 *matp,
-                                           const float4 *texp, const Ray &r, V3 beta, uint32_t path_id, float t_hit,
-                                           uint32_t hit_code, int segment, float4 *__restrict__ sample_rad, Ray &nr, V3 &nbeta) {
+                                           const float4 *texp, const Ray &r, V3 beta, uint32_t chain, uint32_t path_id, float t_hit,
+                                           uint32_t hit_code, int segment, float4 *__restrict__ sample_rad, Ray &nr, V3 &nbeta, uint32_t &nchain) {
     bool alive = false;
     const uint32_t obj_index = hit_code == MISS ? MISS : (hit_code >> sc.prim_bits);
     V3 rad = mk(0.f, 0.f, 0.f);
+    // what the path carries to the camera of a radiance x found at this segment: beta * x, or with the chain the reference's own
+    // nesting a0 * (a1 * (... (a_{k-1} * x))) (render.rs:23-28: `emit + attenuation * color(..)`, emit = 0 on the way)
+    auto carried = [&](V3 x) -> V3 {
+        if (!CHAIN) return beta * x;
+        const uint32_t mask = (1u << f.chain_bits) - 1u;
+        for (int sgm = segment - 1; sgm >= 0; sgm--) {
+            const float4 c = matp[2 * ((chain >> (f.chain_bits * (uint32_t)sgm)) & mask) + 1];
+            x = mk(c.x, c.y, c.z) * x;
+        }
+        return x;
+    };
     if (obj_index == MISS) {
         // render.rs:31; ColorEnv ignores the direction, so its normalisation (sqrt + 3 divisions) is skipped
         V3 dir = sc.env.kind == 0 ? r.d : normalized(r.d);
         if (CHEAP_ONLY) {      // ColorEnv or SkyEnv (environment.rs:21-26,60-67); an HdrEnvironment miss is an expensive case
             DEnv e = sc.env; if (e.kind == 2) e.kind = 0;
-            rad = beta * env_sample(e, dir);
-        } else rad = beta * env_sample(sc.env, dir);
+            rad = carried(env_sample(e, dir));
+        } else rad = carried(env_sample(sc.env, dir));
     } else {
         Obj o = load_obj(objp, obj_index);
         float4 m0 = matp[2 * o.material], m1 = matp[2 * o.material + 1];
@@ -2380,7 +2770,7 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
         V3 texc = mk(m1.x, m1.y, m1.z);                                      // inline ConstantTexture / Metal albedo
         if (!CHEAP_ONLY && !tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
         if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
-            rad = beta * texc;
+            rad = carried(texc);
         } else if (segment < 10) {                                             // render.rs:21
             RngKey key = key_of(f, path_id);
             V3 atten = texc;
@@ -2413,7 +2803,8 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
                 alive = true; break; }
             default: break;
             }
-            nbeta = beta * atten;
+            if (CHAIN) nchain = chain | (o.material << (f.chain_bits * (uint32_t)segment));   // atten IS the material's constant (host: chain_bits)
+            else nbeta = beta * atten;
         }
     }
     // every path deposits exactly once — except zeros over a black environment: k_raygen has already written them, densely
@@ -2444,7 +2835,7 @@ extern __shared__ float4 lds_tables[];
 // of both kinds are compacted into the same output queue; every result is keyed by the path's id, so the order does not matter.
 // MODE 1: the scene has no expensive material or environment at all (cornell, suzanne): the cheap loop alone, the smaller kernel.
 // MODE 0: everything in line (FIREWORK_NO_SHADE_DEFER=1: the A/B baseline, round 2's kernel).
-template <int LDS_TAB, int MODE>   // LDS_TAB 1: object + material + texture tables staged in LDS; 2: materials + textures only (part2: 1 409 objects are 135 KB, its 10 materials are not); 0: none
+template <int LDS_TAB, int MODE, bool CHAIN>   // CHAIN: 8-byte state (load_state_chain);  LDS_TAB 1: object + material + texture tables staged in LDS; 2: materials + textures only (part2: 1 409 objects are 135 KB, its 10 materials are not); 0: none
 // 5 waves per SIMD (96 VGPRs, no spills) instead of the compiler's 4 (114): nothing while the scattered zero deposits bound
 // the kernel (round 1), now cornell k_shade 20.55 -> 20.13 ms (four interleaved pairs), hdri 5.84 -> 5.56, suzanne 4.74 -> 4.57;
 // 6 waves (80 VGPRs) spill three registers and gain nothing more.  Requesting the queue entries TWO chunks ahead (11 more
@@ -2476,52 +2867,54 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     uint32_t out_n = 0;                                                  // survivors written so far (wave-uniform)
     uint32_t list_n = 0;                                                 // MODE 2: entries of shade_list (wave-uniform)
 // ---- K7: compaction inside the wave's private queue: ballot -> mbcnt prefix -> dense stores --------
-    auto compact = [&](bool alive, const Ray &nr, V3 nbeta, uint32_t path_id) {
+    auto compact = [&](bool alive, const Ray &nr, V3 nbeta, uint32_t nchain, uint32_t path_id) {
         const unsigned long long mask = __ballot(alive);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
         if (alive) {
             const uint32_t dst = base + out_n + rank;
             qst(&out.ray_a[dst], make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x));
             qst(&out.ray_b[dst], make_float2(nr.d.y, nr.d.z));
-            qst(&out.state[dst], make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id)));
+            if (CHAIN) qst(&reinterpret_cast<float2 *>(out.state)[dst], make_float2(__uint_as_float(nchain), __uint_as_float(path_id)));
+            else qst(&out.state[dst], make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id)));
         }
         if (f.ex.mode)     // a new ray whose result depends on traversal order: k_extend_exact walks it literally (DExact)
             flag_exact(f.ex, alive && needs_exact(f.ex, nr.o.x, nr.o.y, nr.o.z, nr.d.x, nr.d.y, nr.d.z), base + out_n + rank, segment + 1);
         out_n += (uint32_t)__popcll(mask);
     };
+    auto load_st = [&](uint32_t idx) { return CHAIN ? load_state_chain(in, idx, segment) : load_state(in, idx, segment); };
     auto load_hit = [&](uint32_t idx) { return f.hit4 ? make_float2(0.f, __uint_as_float(reinterpret_cast<const uint32_t *>(hits)[idx])) : qld(&hits[idx]); };
     // MODE 2: the last `take` listed paths, one per lane, with the full shading code
     auto run_list = [&](uint32_t take) {
         bool alive = false;
-        Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
+        Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0, nchain = 0;
         if (lane < take) {
             const uint32_t i = base + shade_list[list_n - take + lane];
-            const float4 ra = qld(&in.ray_a[i]), st = load_state(in, i, segment); const float2 rb = load_ray_b(in, i, f, segment), hr = load_hit(i);
+            const float4 ra = qld(&in.ray_a[i]), st = load_st(i); const float2 rb = load_ray_b(in, i, f, segment), hr = load_hit(i);
             path_id = __float_as_uint(st.w);
-            alive = shade_path<false>(sc, f, objp, matp, texp, make_ray(ra, rb, f, segment), mk(st.x, st.y, st.z), path_id, hr.x, __float_as_uint(hr.y), segment, sample_rad, nr, nbeta);
+            alive = shade_path<false, CHAIN>(sc, f, objp, matp, texp, make_ray(ra, rb, f, segment), mk(st.x, st.y, st.z), __float_as_uint(st.x), path_id, hr.x, __float_as_uint(hr.y), segment, sample_rad, nr, nbeta, nchain);
         }
         list_n -= take;
-        compact(alive, nr, nbeta, path_id);
+        compact(alive, nr, nbeta, nchain, path_id);
     };
     // software pipeline: next chunk's ray / state / hit are in flight while the current chunk is shaded
     float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n; float2 rb_n = make_float2(0, 0), hr_n = rb_n;
-    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); st_n = load_state(in, base + lane, segment); hr_n = load_hit(base + lane); }
+    if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); st_n = load_st(base + lane); hr_n = load_hit(base + lane); }
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
         const uint32_t j = c0 + lane;
         const uint32_t i = base + j;
         float4 ra = ra_n, st = st_n; float2 rb = rb_n, hr = hr_n;
-        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); st_n = load_state(in, i + 64u, segment); hr_n = load_hit(i + 64u); }
+        if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); st_n = load_st(i + 64u); hr_n = load_hit(i + 64u); }
         bool alive = false, later = false;
-        Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0;
+        Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0, nchain = 0;
         if (j < n) {
             Ray r = make_ray(ra, rb, f, segment);
             V3 beta = mk(st.x, st.y, st.z);
             path_id = __float_as_uint(st.w);
             const uint32_t hit_code = __float_as_uint(hr.y);
             if (MODE == 2 && expensive_shading(sc, objp, matp, hit_code)) later = true;
-            else alive = shade_path<MODE != 0>(sc, f, objp, matp, texp, r, beta, path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta);
+            else alive = shade_path<MODE != 0, CHAIN>(sc, f, objp, matp, texp, r, beta, __float_as_uint(st.x), path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta, nchain);
         }
-        compact(alive, nr, nbeta, path_id);
+        compact(alive, nr, nbeta, nchain, path_id);
         if (MODE == 2) {
             const unsigned long long lm = __ballot(later);
             if (lm) {
@@ -2563,7 +2956,7 @@ __global__ __launch_bounds__(EXACT_WB) void k_extend_exact(DScene sc, DFrame f, 
     auto one = [&](uint32_t slot, auto form) {
         const Ray r = make_ray(qld(&in.ray_a[slot]), load_ray_b(in, slot, f, segment), f, segment);
         RngKey key{0, 0, 0};
-        if (sc.has_medium) key = key_of(f, __float_as_uint(load_state(in, slot, segment).w));
+        if (sc.has_medium) key = key_of(f, __float_as_uint(load_home(in, slot, f, segment)));
         float t = 2e9f; uint32_t obj = MISS, prim = 0;
         closest_hit_exact<decltype(form)::value>(sc, r, key, segment, use_bvh != 0, tlas_stack, blas_stack, t, obj, prim);
         const uint32_t code = obj == MISS ? MISS : ((obj << sc.prim_bits) | prim);
@@ -2578,6 +2971,7 @@ __global__ __launch_bounds__(EXACT_WB) void k_extend_exact(DScene sc, DFrame f, 
     }
 }
 
+#if FW_AB
 // ------------------------------------------------------------------------------------------------
 // K2 + K5 + K7 in one launch per segment ("bounce"): every lane intersects its ray and shades the hit while it
 // is still in registers, so the hit record and the second read of the ray never touch HBM (80 B per ray
@@ -2623,9 +3017,11 @@ __global__ __launch_bounds__(WB) void k_bounce(DScene sc, DFrame f, DPaths in, D
             if (sc.has_medium) key = key_of(f, path_id);
             float best_t = 2e9f; uint32_t best_obj = MISS, best_prim = 0;
             bool deferred = false; uint32_t deferred_obj = 0;
-            closest_hit<USE_BVH, false>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj);
+            closest_hit<USE_BVH, false>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj,
+                                        USE_BVH && sc.has_mesh && soft_ray(f.ex, r.d, sc.soft_shear));
             const uint32_t hit_code = best_obj == MISS ? MISS : ((best_obj << sc.prim_bits) | best_prim);
-            alive = shade_path(sc, f, objp, matp, texp, r, mk(st.x, st.y, st.z), path_id, best_t, hit_code, segment, sample_rad, nr, nbeta);
+            uint32_t nchain = 0;
+            alive = shade_path(sc, f, objp, matp, texp, r, mk(st.x, st.y, st.z), 0u, path_id, best_t, hit_code, segment, sample_rad, nr, nbeta, nchain);
         }
         unsigned long long mask = __ballot(alive);
         uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -2639,6 +3035,8 @@ __global__ __launch_bounds__(WB) void k_bounce(DScene sc, DFrame f, DPaths in, D
     }
     if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
 }
+
+#endif   // FW_AB
 
 // per-segment queue totals of one batch (ray statistics): totals[s] += sum_w wcount[s][w]; grid = (slices, segments + 1);
 // the last row sums the waves' parked-ray counts (ptotal, may be null) into totals[MAX_SEGMENTS]
@@ -2874,10 +3272,14 @@ void launch_raygen(const LaunchCfg &c, const DCamera &cam, const DFrame &f, DPat
 // More than 64 KB of dynamic LDS has to be allowed per kernel AND per device (a process may drive several: fw_render_scene_tiled):
 // true the first time kernel group `which` is about to be launched on the current device.
 static bool lds_attr_needed(int which) {
-    static std::atomic<unsigned char> done[2][64];
+    static std::atomic<unsigned char> done[4][64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
     return done[which][dev].exchange(1) == 0;
+}
+// LDS of an LDS-resident walk with `waves` waves per workgroup: tree (+ triangles) + 16-bit stacks + counter + the workgroup's queue counts
+static size_t lds_walk_bytes(size_t tree_bytes, uint32_t waves, uint32_t levels, uint32_t n_queues, uint32_t grid) {
+    return tree_bytes + (size_t)waves * levels * 64 * 2 + 16 + 4 * (size_t)((n_queues + grid - 1) / grid);
 }
 void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, float2 *hits, int segment, bool use_bvh, DPark park) {
     int tl = use_bvh ? c.tlas_depth + 1 : 0;
@@ -2885,21 +3287,44 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     size_t lds = (size_t)levels * WB * sizeof(uint32_t) + (use_bvh && c.has_mesh ? 5 * DEFER_CAP * sizeof(uint32_t) : 0);
     dim3 eg = wave_grid(c);
     const dim3 sg = eg;
+    auto walk_grid = [&](uint32_t waves) { return std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + waves - 1) / waves); };
     if (use_bvh && c.tlas_refill && c.has_mesh) {
         // TLAS walk that parks mesh rays in HBM, then their BLAS walks; a medium around a mesh still walks it in place (blas levels)
         if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<true>, eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park.ray_a, park.ray_b, park.meta, park.pcount, park.stride);
         else hipLaunchKernelGGL(k_extend_tlas_park, sg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
-        // the whole BLAS in LDS when it fits next to sixteen 16-bit stacks (k_blas_lds), else node fetches from L2 (k_blas)
+        // The parked rays' BLAS walks.  WIDE nodes out of LDS where the scene has them (f32, or quantised for a BLAS too big for those):
+        // as many waves per workgroup (16, 12, 8) as fit next to the tree, the triangles too when 16 waves still fit with them.
+        if (c.lds_trees && c.wblas_fmt != WIDE_NONE && sc.wblas && c.max_tris < 0x7fffu) {
+            const uint32_t wl = 3u * c.wblas_depth + 2u;
+            const size_t tree = (size_t)c.wblas_nodes * (c.wblas_fmt == WIDE_F32 ? WIDE_F32_DW : WIDE_Q8_DW) * 4, tris = (size_t)c.n_tris * 48;
+            uint32_t waves = 0; bool lds_tris = false;
+            if (!c.no_lds_tris && lds_walk_bytes(tree + tris, 16, wl, c.q.n_waves, walk_grid(16)) <= LDS_TREE_LIMIT) { waves = 16; lds_tris = true; }
+            else for (uint32_t w : {16u, 12u, 8u}) if (lds_walk_bytes(tree, w, wl, c.q.n_waves, walk_grid(w)) <= LDS_TREE_LIMIT) { waves = w; break; }
+            if (waves) {
+                if (lds_attr_needed(2)) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_wide<WIDE_F32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_wide<WIDE_F32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_wide<WIDE_Q8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_wide<WIDE_Q8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                }
+                const dim3 lg(walk_grid(waves));
+                const size_t bytes = lds_walk_bytes(tree + (lds_tris ? tris : 0), waves, wl, c.q.n_waves, lg.x);
+#define FW_BLAS_WIDE(F, T) hipLaunchKernelGGL((k_blas_wide<F, T>), lg, dim3(waves * 64), bytes, c.stream, sc, park, hits, c.q, c.wblas_nodes, c.n_tris, wl)
+                if (c.wblas_fmt == WIDE_F32) { if (lds_tris) FW_BLAS_WIDE(WIDE_F32, true); else FW_BLAS_WIDE(WIDE_F32, false); }
+                else { if (lds_tris) FW_BLAS_WIDE(WIDE_Q8, true); else FW_BLAS_WIDE(WIDE_Q8, false); }
+#undef FW_BLAS_WIDE
+                return;
+            }
+        }
+        // pair nodes: the whole BLAS in LDS when it fits next to sixteen 16-bit stacks (k_blas_lds), else node fetches from L2 (k_blas)
         const uint32_t bl = (uint32_t)c.blas_depth + 1u;
-        const uint32_t lds_grid = std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES);       // workgroups of the LDS walks
-        const size_t lds_queue_counts = 16 + 4 * (size_t)((c.q.n_waves + lds_grid - 1) / lds_grid);                          // counter + the workgroup's queue counts
-        const size_t lds_blas = (size_t)c.blas_pair_nodes * 64 + (size_t)LDS_WAVES * bl * 64 * 2 + lds_queue_counts, lds_tris = (size_t)c.n_tris * 48;
+        const size_t lds_blas = lds_walk_bytes((size_t)c.blas_pair_nodes * 64, LDS_WAVES, bl, c.q.n_waves, walk_grid(LDS_WAVES)), lds_tris = (size_t)c.n_tris * 48;
         if (c.lds_trees && c.blas_pair_nodes > 0 && c.blas_pair_nodes < 32768u && c.max_tris < 32768u && lds_blas <= LDS_TREE_LIMIT) {
             if (lds_attr_needed(0)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_blas_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
             }
-            const dim3 lg(std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES));
+            const dim3 lg(walk_grid(LDS_WAVES));
             if (lds_blas + lds_tris <= LDS_TREE_LIMIT && !c.no_lds_tris)      // the triangles too, when they fit as well
                 hipLaunchKernelGGL(k_blas_lds<true>, lg, dim3(LDS_WAVES * 64), lds_blas + lds_tris, c.stream, sc, park, hits, c.q, c.blas_pair_nodes, c.n_tris, bl);
             else
@@ -2908,18 +3333,31 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
         else hipLaunchKernelGGL(k_blas, sg, dim3(WB), (size_t)(c.blas_depth + 1) * WB * sizeof(uint32_t), c.stream, sc, park, hits, c.q);
     }
     else if (use_bvh && c.tlas_refill) {
-        // scenes without meshes: the whole TLAS in LDS when it fits next to sixteen 16-bit stacks
-        const uint32_t lds_grid = std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES);
-        const size_t lds_tlas = (size_t)c.tlas_pair_nodes * 64 + (size_t)LDS_WAVES * (uint32_t)tl * 64 * 2 + 16 + 4 * (size_t)((c.q.n_waves + lds_grid - 1) / lds_grid);
+        // scenes without meshes: the whole TLAS in LDS when it fits next to the walks' stacks — WIDE nodes where the scene has them
+        if (c.lds_trees && !c.has_mesh && sc.n_objects > TLAS_SCAN_MAX && c.wtlas_fmt == WIDE_F32 && sc.wtlas && sc.n_objects < 0x7fffu) {
+            const uint32_t wl = 3u * c.wtlas_depth + 2u;
+            const size_t tree = (size_t)c.wtlas_nodes * WIDE_F32_DW * 4;
+            uint32_t waves = 0;
+            for (uint32_t w : {16u, 12u, 8u}) if (lds_walk_bytes(tree, w, wl, c.q.n_waves, walk_grid(w)) <= LDS_TREE_LIMIT) { waves = w; break; }
+            if (waves) {
+                if (lds_attr_needed(3)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                const dim3 lg(walk_grid(waves));
+                hipLaunchKernelGGL(k_extend_tlas_wide, lg, dim3(waves * 64), lds_walk_bytes(tree, waves, wl, c.q.n_waves, lg.x), c.stream, sc, f, in, hits, c.q, segment, c.wtlas_nodes, wl);
+                return;
+            }
+        }
+        const size_t lds_tlas = lds_walk_bytes((size_t)c.tlas_pair_nodes * 64, LDS_WAVES, (uint32_t)tl, c.q.n_waves, walk_grid(LDS_WAVES));
         if (c.lds_trees && !c.has_mesh && sc.n_objects > TLAS_SCAN_MAX && c.tlas_pair_nodes < 32768u && sc.n_objects < 32768u && lds_tlas <= LDS_TREE_LIMIT) {
             if (lds_attr_needed(1)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
-            hipLaunchKernelGGL(k_extend_tlas_lds, dim3(std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + LDS_WAVES - 1) / LDS_WAVES)), dim3(LDS_WAVES * 64), lds_tlas, c.stream,
+            hipLaunchKernelGGL(k_extend_tlas_lds, dim3(walk_grid(LDS_WAVES)), dim3(LDS_WAVES * 64), lds_tlas, c.stream,
                                sc, f, in, hits, c.q, segment, c.tlas_pair_nodes, (uint32_t)tl);
         }
         else if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, (float4 *)nullptr, (float2 *)nullptr, (float4 *)nullptr, (uint32_t *)nullptr, 0u);
         else hipLaunchKernelGGL(k_extend_tlas, sg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     }
+#if FW_AB
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+#endif
     else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)(DEFER0_CAP + DEFER1_CAP) * 12, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
@@ -2942,12 +3380,19 @@ void launch_shade(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths 
     const size_t lds = lt == 1 ? tab : (lt == 2 ? tab_mt : 0);
     // shading mode (k_shade): 0 everything in line | 1 the scene has nothing expensive | 2 expensive paths through the list
     const int mode = c.shade_mode;
-#define FW_SHADE(L, M) hipLaunchKernelGGL((k_shade<L, M>), wave_grid(c), dim3(WB), lds, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex)
-#define FW_SHADE_L(L) do { if (mode == 2) FW_SHADE(L, 2); else if (mode == 1) FW_SHADE(L, 1); else FW_SHADE(L, 0); } while (0)
+#define FW_SHADE(L, M, C) hipLaunchKernelGGL((k_shade<L, M, C>), wave_grid(c), dim3(WB), lds, c.stream, sc, f, in, out, hits, sample_rad, c.q, segment, c.n_mat, c.n_tex)
+#define FW_SHADE_C(L, M) do { if (f.chain_bits) FW_SHADE(L, M, true); else FW_SHADE(L, M, false); } while (0)
+#if FW_AB
+#define FW_SHADE_L(L) do { if (mode == 2) FW_SHADE(L, 2, false); else if (mode == 1) FW_SHADE_C(L, 1); else FW_SHADE_C(L, 0); } while (0)
+#else
+#define FW_SHADE_L(L) do { if (mode == 1) FW_SHADE_C(L, 1); else FW_SHADE_C(L, 0); } while (0)
+#endif
     if (lt == 1) FW_SHADE_L(1); else if (lt == 2) FW_SHADE_L(2); else FW_SHADE_L(0);
 #undef FW_SHADE_L
+#undef FW_SHADE_C
 #undef FW_SHADE
 }
+#if FW_AB
 void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths in, DPaths out, float4 *sample_rad,
                    int segment, bool use_bvh) {
     size_t tab = ((size_t)sc.n_objects * OBJ_Q + 2 * (size_t)c.n_mat + 2 * (size_t)c.n_tex) * sizeof(float4);
@@ -2963,6 +3408,7 @@ void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else { if (lds_tab) FW_BOUNCE(false, true); else FW_BOUNCE(false, false); }
 #undef FW_BOUNCE
 }
+#endif   // FW_AB
 #ifdef FW_TRAV_STATS
 extern "C" int fw_debug_trav_stats(unsigned long long out[8]) {   // debug builds only; reads and clears the counters
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <mutex>
 #include <new>
 #include <string>
@@ -27,6 +28,80 @@ namespace {
 thread_local std::string g_last_error;
 
 int fail(int status, const std::string &msg) { g_last_error = msg; return status; }
+
+// ---- options: every runtime switch of the library.  The environment (FIREWORK_<NAME>) is read ONCE, when the library is loaded;
+// fw_set_option changes one afterwards (tests, tools/).  Nothing on the render path calls getenv, and the product build carries
+// no switch for a kernel it does not carry.
+struct Options {
+    bool bvh_median = false;      // BVH=median: walk the reference's own topology (parity / A-B mode)
+    bool no_exact = false, exact_all = false;   // NO_EXACT: no literal walk at all; EXACT_ALL=1: every ray takes it (the renderer then IS bvh.rs:115-151)
+    int exact_form = 0;           // EXACT_FORM=lane|wave
+    bool no_defer = false, no_hit4 = false, no_hoist = false, no_lds_tables = false, no_lds_trees = false, no_lds_tris = false, no_short_rays = false,
+         no_tile_order = false, no_zero_skip = false, dep_pixel_major = false, dep_slot_major = false, trace = false, no_chain = false;
+    int streams = 0;              // STREAMS=n batches in flight (0: the library's choice)
+    int soft_shear_log2 = 5, exact_shear_log2 = 10; double exact_far_x = 1024.0;   // SOFT_SHEAR_LOG2 (0: off), EXACT_SHEAR_LOG2, EXACT_FAR_X: the flag rules' thresholds (tools/flag_margin.py)
+    int wide = -1;                // WIDE=0|f32|q8: no wide nodes / force an encoding (-1: by size)
+    long waves = 0;               // WAVES=n wave queues (0: the library's choice)
+    long long paths_per_batch = 0;
+    std::string dump_path;        // DUMP_PATH=file (tools/diverge.py)
+#if FW_AB
+    bool fused = false, tlas_refill_off = false, shade_list = false, no_shade_defer = false, stagger = false;
+#endif
+};
+const char *const OPTION_NAMES[] = {"BVH", "NO_EXACT", "EXACT_ALL", "EXACT_FORM", "NO_DEFER", "NO_HIT4", "NO_HOIST", "NO_LDS_TABLES", "NO_LDS_TREES", "NO_LDS_TRIS",
+                                    "NO_SHORT_RAYS", "NO_TILE_ORDER", "NO_ZERO_SKIP", "DEP_PIXEL_MAJOR", "DEP_SLOT_MAJOR", "NO_CHAIN", "SOFT_SHEAR_LOG2", "EXACT_SHEAR_LOG2", "EXACT_FAR_X", "TRACE", "STREAMS", "WIDE", "WAVES",
+                                    "PATHS_PER_BATCH", "DUMP_PATH",
+#if FW_AB
+                                    "FUSED", "TLAS_REFILL", "SHADE_LIST", "NO_SHADE_DEFER", "STAGGER",
+#endif
+                                    nullptr};
+bool option_apply(Options &o, const char *name, const char *v) {      // v == nullptr: back to the default
+    const std::string n = name;
+    auto on = [&] { return v != nullptr; };
+    auto num = [&] { return v ? atoll(v) : 0ll; };
+    if (n == "BVH") o.bvh_median = v && std::strcmp(v, "median") == 0;
+    else if (n == "NO_EXACT") o.no_exact = on();
+    else if (n == "EXACT_ALL") o.exact_all = num() != 0;
+    else if (n == "EXACT_FORM") o.exact_form = v ? (std::strcmp(v, "lane") == 0 ? 1 : (std::strcmp(v, "wave") == 0 ? 2 : 0)) : 0;
+    else if (n == "NO_DEFER") o.no_defer = on();
+    else if (n == "NO_HIT4") o.no_hit4 = on();
+    else if (n == "NO_HOIST") o.no_hoist = on();
+    else if (n == "NO_LDS_TABLES") o.no_lds_tables = on();
+    else if (n == "NO_LDS_TREES") o.no_lds_trees = on();
+    else if (n == "NO_LDS_TRIS") o.no_lds_tris = on();
+    else if (n == "NO_SHORT_RAYS") o.no_short_rays = on();
+    else if (n == "NO_TILE_ORDER") o.no_tile_order = on();
+    else if (n == "NO_ZERO_SKIP") o.no_zero_skip = on();
+    else if (n == "DEP_PIXEL_MAJOR") o.dep_pixel_major = on();
+    else if (n == "DEP_SLOT_MAJOR") o.dep_slot_major = on();
+    else if (n == "NO_CHAIN") o.no_chain = on();
+    else if (n == "SOFT_SHEAR_LOG2") o.soft_shear_log2 = v ? (int)num() : 5;
+    else if (n == "EXACT_SHEAR_LOG2") o.exact_shear_log2 = v ? (int)num() : 10;
+    else if (n == "EXACT_FAR_X") o.exact_far_x = v ? atof(v) : 1024.0;
+    else if (n == "TRACE") o.trace = on();
+    else if (n == "STREAMS") o.streams = (int)std::max<long long>(0, num());
+    else if (n == "WIDE") o.wide = !v ? -1 : (std::strcmp(v, "0") == 0 ? 0 : (std::strcmp(v, "f32") == 0 ? 1 : (std::strcmp(v, "q8") == 0 ? 2 : -1)));
+    else if (n == "WAVES") o.waves = (long)std::max<long long>(0, num());
+    else if (n == "PATHS_PER_BATCH") o.paths_per_batch = std::max<long long>(0, num());
+    else if (n == "DUMP_PATH") o.dump_path = v ? v : "";
+#if FW_AB
+    else if (n == "FUSED") o.fused = num() != 0;
+    else if (n == "TLAS_REFILL") o.tlas_refill_off = v && atoi(v) == 0;
+    else if (n == "SHADE_LIST") o.shade_list = on();
+    else if (n == "NO_SHADE_DEFER") o.no_shade_defer = on();
+    else if (n == "STAGGER") o.stagger = on();
+#endif
+    else return false;
+    return true;
+}
+Options options_from_env() {
+    Options o;
+    for (int k = 0; OPTION_NAMES[k]; k++) { const std::string e = std::string("FIREWORK_") + OPTION_NAMES[k]; if (const char *v = getenv(e.c_str())) option_apply(o, OPTION_NAMES[k], v); }
+    return o;
+}
+std::mutex g_opt_mu;
+Options g_opt = options_from_env();          // once, at load
+Options options() { std::lock_guard<std::mutex> g(g_opt_mu); return g_opt; }
 
 #define HIPCHK(expr)                                                                                           \
     do {                                                                                                       \
@@ -125,6 +200,17 @@ std::vector<uint32_t> reference_ranks(const FlatBvh &ref, size_t n_items) {
         else if (kind == fw::NODE_DOUBLE) { rank[A & fw::NODE_MASK] = next++; rank[B] = next++; }
     }
     return rank;
+}
+
+// item boxes := the box of the reference leaf node that holds the item (its own box for a Leaf, the union for a DoubleLeaf)
+void leaf_node_boxes(const FlatBvh &ref, std::vector<Box> &boxes) {
+    for (uint32_t i = 0; i < ref.count(); i++) {
+        const float *nd = &ref.nodes[(size_t)i * 8];
+        uint32_t A, B; std::memcpy(&A, nd + 3, 4); std::memcpy(&B, nd + 7, 4);
+        if ((A >> 30) != fw::NODE_DOUBLE) continue;
+        const Box nb{{nd[0], nd[1], nd[2]}, {nd[4], nd[5], nd[6]}};
+        boxes[A & fw::NODE_MASK] = nb; boxes[B] = nb;
+    }
 }
 
 // ---- traversal tree: binned-SAH top-down build, same node format (leaves of 1 or 2 items, DFS order).
@@ -243,7 +329,186 @@ static uint32_t pair_convert(const FlatBvh &src, const std::vector<Box> &item_bo
     out.depth = std::max(out.depth, local.depth);
     return ref;
 }
-inline bool use_sah() { const char *e = getenv("FIREWORK_BVH"); return !(e && std::strcmp(e, "median") == 0); }
+inline bool use_sah() { return !options().bvh_median; }
+
+// ---- WIDE nodes (fw_device.h): the tree the LDS-resident walks step through since round 4 — four children per node, collapsed
+// from the same binary tree the pair nodes come from (a child is opened, largest box first, until four are held; a DoubleLeaf
+// opens into its two items with their own boxes).  One step decides four boxes for one stack operation and one trip round the
+// walk's loop, and the tree has a third of the pair tree's nodes.  Two encodings of the same topology:
+//   WIDE_F32 (112 B)  the children's boxes as they are, SoA by plane: the slab test is the pair walk's, an item is reached iff its
+//                     own box passes aabb.rs:30-50 — bit for bit what the pair walk decides;
+//   WIDE_Q8  (48 B)   boxes quantised to 8 bits per plane relative to the node (origin + q * 2^e per axis), rounded OUTWARD and
+//                     checked here with the device's own dequantisation (one fma): a superset of the exact box under the same
+//                     monotone slab arithmetic, so no item the exact boxes admit is ever culled.  For trees whose f32 nodes do
+//                     not fit a CU's LDS (teapot.yml: 6 320 triangles = 236 KB as f32 nodes, 101 KB quantised).
+struct WideBvh {
+    std::vector<uint32_t> words;   // fw::WIDE_F32_DW or fw::WIDE_Q8_DW dwords per node
+    int fmt = 0;
+    uint32_t depth = 0;            // wide nodes on the longest root-to-leaf path
+    uint32_t dw() const { return fmt == fw::WIDE_Q8 ? fw::WIDE_Q8_DW : fw::WIDE_F32_DW; }
+    uint32_t count() const { return (uint32_t)(words.size() / dw()); }
+};
+struct WideChild { bool leaf; uint32_t id; Box box; };   // id: item, or node index in the source FlatBvh
+static void wide_children_of(const FlatBvh &src, uint32_t i, const std::vector<Box> &item_boxes, std::vector<WideChild> &out) {
+    const float *nd = &src.nodes[(size_t)i * 8];
+    uint32_t A, B; std::memcpy(&A, nd + 3, 4); std::memcpy(&B, nd + 7, 4);
+    const uint32_t kind = A >> 30;
+    auto child = [&](uint32_t c) {
+        const float *cn = &src.nodes[(size_t)c * 8];
+        uint32_t cA; std::memcpy(&cA, cn + 3, 4);
+        if ((cA >> 30) == fw::NODE_LEAF) out.push_back({true, cA & fw::NODE_MASK, item_boxes[cA & fw::NODE_MASK]});
+        else out.push_back({false, c, Box{{cn[0], cn[1], cn[2]}, {cn[4], cn[5], cn[6]}}});
+    };
+    if (kind == fw::NODE_DOUBLE) { out.push_back({true, A & fw::NODE_MASK, item_boxes[A & fw::NODE_MASK]}); out.push_back({true, B, item_boxes[B]}); }
+    else { child(i + 1); child(A & fw::NODE_MASK); }
+}
+inline uint32_t f_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+// one axis of a WIDE_Q8 node: exponent byte e (scale 2^(e-127)) and the children's quantised planes, rounded outward
+static bool wide_quantise_axis(const float *lo, const float *hi, int n, float org, uint32_t &e_out, uint8_t *qlo, uint8_t *qhi) {
+    float ext = 0.f;
+    for (int c = 0; c < n; c++) { if (!(lo[c] >= org) || !(hi[c] >= lo[c]) || !std::isfinite(hi[c])) return false; ext = std::fmax(ext, hi[c] - org); }
+    int e = 1;                                               // smallest scale with every plane <= 254 quanta from the origin (255 is kept for the rounding step)
+    if (ext > 0.f) { int ex; std::frexp(ext / 254.f, &ex); e = std::max(1, std::min(254, ex + 127)); }
+    for (; e <= 254; e++) {
+        const float s = bits_f((uint32_t)e << 23);
+        bool ok = true;
+        for (int c = 0; c < n && ok; c++) {
+            double ql = std::floor(((double)lo[c] - (double)org) / (double)s), qh = std::ceil(((double)hi[c] - (double)org) / (double)s);
+            if (ql < 0) ql = 0;
+            if (ql > 255 || qh > 255) { ok = false; break; }
+            int a = (int)ql, b = (int)qh;
+            while (a > 0 && std::fmaf((float)a, s, org) > lo[c]) a--;          // the device's own dequantisation: one fma
+            while (b < 255 && std::fmaf((float)b, s, org) < hi[c]) b++;
+            if (std::fmaf((float)a, s, org) > lo[c] || std::fmaf((float)b, s, org) < hi[c]) { ok = false; break; }
+            qlo[c] = (uint8_t)a; qhi[c] = (uint8_t)b;
+        }
+        if (ok) { e_out = (uint32_t)e; return true; }
+    }
+    return false;
+}
+// returns the node's index in `out` (relative to `base` nodes of other trees already there), or 0xffffffff when the tree cannot be encoded
+static uint32_t wide_build_rec(const FlatBvh &src, uint32_t flat, const std::vector<Box> &item_boxes, WideBvh &out, uint32_t base, uint32_t depth) {
+    std::vector<WideChild> ch;
+    wide_children_of(src, flat, item_boxes, ch);
+    while (ch.size() < 4) {                                  // open the inner child with the largest box
+        int pick = -1; float best = -1.f;
+        for (size_t k = 0; k < ch.size(); k++) if (!ch[k].leaf) { const float a = box_area(ch[k].box); if (pick < 0 || a > best) { pick = (int)k; best = a; } }
+        if (pick < 0) break;
+        const WideChild open = ch[pick];
+        ch.erase(ch.begin() + pick);
+        wide_children_of(src, open.id, item_boxes, ch);
+    }
+    const uint32_t me = out.count(), dw = out.dw();
+    out.words.resize(out.words.size() + dw, 0u);
+    out.depth = std::max(out.depth, depth + 1);
+    uint32_t refs[4];
+    const int n = (int)ch.size();
+    for (int c = 0; c < n; c++) {
+        if (ch[c].leaf) { if (ch[c].id >= 0x7fffu) return 0xffffffffu; refs[c] = fw::W_LEAF | ch[c].id; }
+        else {
+            const uint32_t r = wide_build_rec(src, ch[c].id, item_boxes, out, base, depth + 1);
+            if (r == 0xffffffffu || base + r >= 0x8000u) return 0xffffffffu;
+            refs[c] = base + r;
+        }
+    }
+    for (int c = n; c < 4; c++) refs[c] = refs[0];           // a free slot repeats child 0 behind a box no finite ray can hit
+    uint32_t *w = &out.words[(size_t)me * dw];
+    if (out.fmt == fw::WIDE_F32) {                            // planes: lo.x[4] lo.y[4] lo.z[4] hi.x[4] hi.y[4] hi.z[4], then the refs
+        const float INF = std::numeric_limits<float>::infinity();
+        for (int c = 0; c < 4; c++) {
+            const bool on = c < n;
+            const Box &b = ch[on ? c : 0].box;
+            w[0 + c] = f_bits(on ? b.mn.x : INF); w[4 + c] = f_bits(on ? b.mn.y : INF); w[8 + c] = f_bits(on ? b.mn.z : INF);
+            w[12 + c] = f_bits(on ? b.mx.x : -INF); w[16 + c] = f_bits(on ? b.mx.y : -INF); w[20 + c] = f_bits(on ? b.mx.z : -INF);
+        }
+        w[24] = refs[0] | (refs[1] << 16); w[25] = refs[2] | (refs[3] << 16); w[26] = w[27] = 0u;
+    } else {
+        V3 org = ch[0].box.mn;
+        for (int c = 1; c < n; c++) org = vmin(org, ch[c].box.mn);
+        uint32_t e[3]; uint8_t ql[3][4], qh[3][4];
+        for (int a = 0; a < 3; a++) {
+            float lo[4], hi[4];
+            for (int c = 0; c < n; c++) { lo[c] = ch[c].box.mn[a]; hi[c] = ch[c].box.mx[a]; }
+            if (!wide_quantise_axis(lo, hi, n, org[a], e[a], ql[a], qh[a])) return 0xffffffffu;
+            for (int c = n; c < 4; c++) { ql[a][c] = 255; qh[a][c] = 0; }
+        }
+        w[0] = f_bits(org.x); w[1] = f_bits(org.y); w[2] = f_bits(org.z); w[3] = e[0] | (e[1] << 8) | (e[2] << 16);
+        for (int a = 0; a < 3; a++) {
+            w[4 + a] = (uint32_t)ql[a][0] | ((uint32_t)ql[a][1] << 8) | ((uint32_t)ql[a][2] << 16) | ((uint32_t)ql[a][3] << 24);
+            w[8 + a] = (uint32_t)qh[a][0] | ((uint32_t)qh[a][1] << 8) | ((uint32_t)qh[a][2] << 16) | ((uint32_t)qh[a][3] << 24);
+        }
+        w[7] = refs[0] | (refs[1] << 16); w[11] = refs[2] | (refs[3] << 16);
+    }
+    return me;
+}
+// appends the wide form of `src` to `out`; returns its root reference (a node, or W_LEAF | item for a one-item tree), 0xffffffff on failure
+static uint32_t wide_convert(const FlatBvh &src, const std::vector<Box> &item_boxes, WideBvh &out) {
+    uint32_t A; std::memcpy(&A, &src.nodes[3], 4);
+    if ((A >> 30) == fw::NODE_LEAF) return (A & fw::NODE_MASK) < 0x7fffu ? (fw::W_LEAF | (A & fw::NODE_MASK)) : 0xffffffffu;
+    WideBvh local; local.fmt = out.fmt;
+    const uint32_t base = out.count();
+    const uint32_t r = wide_build_rec(src, 0, item_boxes, local, base, 0);
+    if (r == 0xffffffffu) return r;
+    out.words.insert(out.words.end(), local.words.begin(), local.words.end());
+    out.depth = std::max(out.depth, local.depth);
+    return base + r;
+}
+// Every invariant the walks rely on, checked on the finished tree (fw_selftest_wide_bvh; the CPU test suite runs it on the
+// reference's meshes): each item is the leaf of exactly one slot, a child's box as the DEVICE decodes it contains the exact box,
+// node references point forward, free slots cannot be hit.  Returns the number of violations.
+static uint32_t wide_check(const WideBvh &t, uint32_t root, const std::vector<Box> &item_boxes, uint32_t stats[4]) {
+    uint32_t bad = 0, leaves = 0, free_slots = 0;
+    std::vector<uint32_t> seen(item_boxes.size(), 0);
+    if (root & fw::W_LEAF) { stats[0] = 0; stats[1] = 1; stats[2] = 0; stats[3] = 0; return (root & 0x7fffu) == 0 && item_boxes.size() == 1 ? 0u : 1u; }
+    struct Rec { uint32_t node; Box bound; bool has_bound; };
+    std::vector<Rec> todo{{root, Box{}, false}};
+    std::vector<uint32_t> visited(t.count(), 0);
+    auto subtree_box = [&](auto &&self, uint32_t ref) -> Box {
+        if (ref & fw::W_LEAF) return item_boxes[ref & 0x7fffu];
+        const uint32_t *w = &t.words[(size_t)ref * t.dw()];
+        const uint32_t r[4] = {(t.fmt == fw::WIDE_F32 ? w[24] : w[7]) & 0xffffu, (t.fmt == fw::WIDE_F32 ? w[24] : w[7]) >> 16,
+                               (t.fmt == fw::WIDE_F32 ? w[25] : w[11]) & 0xffffu, (t.fmt == fw::WIDE_F32 ? w[25] : w[11]) >> 16};
+        Box b = self(self, r[0]);
+        for (int c = 1; c < 4; c++) if (r[c] != r[0]) b = box_union(b, self(self, r[c]));
+        return b;
+    };
+    while (!todo.empty()) {
+        const Rec rec = todo.back(); todo.pop_back();
+        if (rec.node >= t.count() || visited[rec.node]++) { bad++; continue; }
+        const uint32_t *w = &t.words[(size_t)rec.node * t.dw()];
+        uint32_t r[4]; Box dec[4];
+        if (t.fmt == fw::WIDE_F32) {
+            r[0] = w[24] & 0xffffu; r[1] = w[24] >> 16; r[2] = w[25] & 0xffffu; r[3] = w[25] >> 16;
+            for (int c = 0; c < 4; c++) dec[c] = Box{{bits_f(w[c]), bits_f(w[4 + c]), bits_f(w[8 + c])}, {bits_f(w[12 + c]), bits_f(w[16 + c]), bits_f(w[20 + c])}};
+        } else {
+            r[0] = w[7] & 0xffffu; r[1] = w[7] >> 16; r[2] = w[11] & 0xffffu; r[3] = w[11] >> 16;
+            const float org[3] = {bits_f(w[0]), bits_f(w[1]), bits_f(w[2])};
+            for (int c = 0; c < 4; c++) {
+                float lo[3], hi[3];
+                for (int a = 0; a < 3; a++) {
+                    const float s = bits_f(((w[3] >> (8 * a)) & 0xffu) << 23);
+                    lo[a] = std::fmaf((float)((w[4 + a] >> (8 * c)) & 0xffu), s, org[a]);
+                    hi[a] = std::fmaf((float)((w[8 + a] >> (8 * c)) & 0xffu), s, org[a]);
+                }
+                dec[c] = Box{{lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]}};
+            }
+        }
+        for (int c = 0; c < 4; c++) {
+            const bool is_free = c > 0 && r[c] == r[0];
+            if (is_free) { free_slots++; if (!(dec[c].mn.x > dec[c].mx.x && dec[c].mn.y > dec[c].mx.y && dec[c].mn.z > dec[c].mx.z)) bad++; continue; }
+            const Box exact = subtree_box(subtree_box, r[c]);
+            if (!(dec[c].mn.x <= exact.mn.x && dec[c].mn.y <= exact.mn.y && dec[c].mn.z <= exact.mn.z &&
+                  dec[c].mx.x >= exact.mx.x && dec[c].mx.y >= exact.mx.y && dec[c].mx.z >= exact.mx.z)) bad++;
+            if (t.fmt == fw::WIDE_F32 && (r[c] & fw::W_LEAF) && std::memcmp(&dec[c], &item_boxes[r[c] & 0x7fffu], sizeof(Box)) != 0) bad++;   // an item's own box, bit for bit
+            if (r[c] & fw::W_LEAF) { const uint32_t it = r[c] & 0x7fffu; if (it >= seen.size() || seen[it]++) bad++; leaves++; }
+            else { if (r[c] <= rec.node) bad++; todo.push_back({r[c], Box{}, false}); }
+        }
+    }
+    for (uint32_t s : seen) if (s != 1) bad++;
+    for (uint32_t v : visited) if (v != 1) bad++;
+    stats[0] = t.count(); stats[1] = leaves; stats[2] = free_slots; stats[3] = t.depth;
+    return bad;
+}
 
 // ---- device allocations owned by a scene / workspace ----------------------------------------------------
 struct DevBuf {
@@ -333,6 +598,9 @@ struct fw_scene {
     uint32_t tlas_nodes = 0, blas_nodes = 0, tlas_depth = 0, blas_depth = 0, n_mat = 0, n_tex = 0;
     uint32_t blas_pair_nodes = 0, tlas_pair_nodes = 0, max_tris = 0, n_tris = 0;
     uint32_t n_defer = 0;
+    uint32_t chain_bits = 0;                // != 0: the scene's paths can carry their material ids instead of a running product (DFrame.chain_bits)
+    int wblas_fmt = 0, wtlas_fmt = 0;       // fw::WIDE_*: the encoding of the wide trees uploaded with this scene (0: none)
+    uint32_t wblas_nodes = 0, wtlas_nodes = 0, wblas_depth = 0, wtlas_depth = 0;
     bool has_expensive = false;   // some material is a dielectric or carries a non-constant texture, or the environment is an HDR map (k_shade's list)
     bool simple_shapes = false;   // every object is a sphere, an axis-aligned rect or a Rect3d (no medium, mesh, cone, cylinder, disk)
     bool hdr_env = false;
@@ -346,18 +614,22 @@ struct fw_scene {
 namespace {
 
 struct ShapeParams { float q3[4] = {0, 0, 0, 0}, q4[4] = {0, 0, 0, 0}; uint32_t kind = 0, flags = 0, aux0 = 0, aux1 = 0; Box box{};
+                     uint32_t wroot_f32 = 0xffffffffu, wroot_q8 = 0xffffffffu;   // meshes: root reference of the wide tree in either encoding
                      uint32_t ref_root = 0xffffffffu, n_tris = 0;   // meshes: first node of the reference tree in Flattener::ref_blas
                      Box true_box{}; };   // OF_GATE shapes: a box that really encloses the geometry (object space)
 
 struct Flattener {
     const fw_scene_desc *d;
     std::vector<float> tri, tri_attr;     // 12 floats per triangle each
+    std::vector<float> tri_gate;          // 8 floats per triangle: the box of its leaf node in the REFERENCE tree of its mesh (own box, or a DoubleLeaf's union)
     std::vector<uint32_t> tri_rank;       // in-order rank of each triangle in the reference tree of its mesh
     bool any_attr = false;
     PairBvh blas;                 // all meshes' trees, as walked on the device
     std::vector<float> ref_blas;  // all meshes' REFERENCE trees (FlatBvh nodes, 8 floats each; child indices relative to the mesh's first node)
     uint32_t ref_blas_depth = 0;
     uint32_t blas_depth = 0, ref_blas_nodes = 0, max_tris = 0;
+    WideBvh wblas_f32, wblas_q8;  // all meshes' trees as WIDE nodes, both encodings
+    bool wide_ok[2] = {true, true};
     std::vector<ShapeParams> mesh_cache;  // per shape index: a TriangleMesh shape referenced by several objects (or by a medium
     std::vector<uint8_t> mesh_cached;     // and an object) is flattened and built once, every user shares its triangles and BLAS
 
@@ -470,10 +742,32 @@ struct Flattener {
         sp.ref_root = (uint32_t)(ref_blas.size() / 8); sp.n_tris = n_tris;
         ref_blas.insert(ref_blas.end(), local.nodes.begin(), local.nodes.end());
         ref_blas_depth = std::max(ref_blas_depth, local.depth);
+        // Round 4: the reference tests a triangle iff the ray passes every box down to its LEAF NODE, i.e. iff it passes that node's box
+        // (bvh.rs:44-52: a DoubleLeaf's two triangles sit behind the union; the ancestors' boxes are supersets under the monotone slab
+        // arithmetic).  The walked trees keep the triangles' own, tight boxes — walking the unions costs 30 % (gpurun_out/r04d) — and
+        // every hit that would become a ray's best is checked against this rule before it counts (fw_kernels.hip: tri_gate_ok):
+        // tri_gate holds each triangle's reference leaf-node box.
+        {
+            std::vector<Box> gboxes = boxes;
+            leaf_node_boxes(local, gboxes);
+            tri_gate.resize(tri.size() / 12 * 8, 0.f);
+            for (uint32_t t = 0; t < n_tris; t++) {
+                float *g = &tri_gate[(size_t)(tri_base + t) * 8];
+                g[0] = gboxes[t].mn.x; g[1] = gboxes[t].mn.y; g[2] = gboxes[t].mn.z; g[4] = gboxes[t].mx.x; g[5] = gboxes[t].mx.y; g[6] = gboxes[t].mx.z;
+            }
+        }
         if (use_sah()) { FlatBvh sah; sah_build(sah, boxes); local = std::move(sah); }
         uint32_t root = pair_convert(local, boxes, blas);     // root reference into the shared BLAS array
         blas_depth = blas.depth;
         sp.aux0 = root; sp.aux1 = tri_base;
+        for (int f = 0; f < 2; f++) {                         // the same tree as WIDE nodes, in both encodings (create_scene_impl keeps one, or none)
+            WideBvh &wb = f == 0 ? wblas_f32 : wblas_q8;
+            if (wb.fmt == 0) wb.fmt = f == 0 ? fw::WIDE_F32 : fw::WIDE_Q8;
+            if (!wide_ok[f]) continue;
+            const uint32_t wr = wide_convert(local, boxes, wb);
+            if (wr == 0xffffffffu) wide_ok[f] = false;
+            (f == 0 ? sp.wroot_f32 : sp.wroot_q8) = wr;
+        }
         if (s.normals) sp.flags |= fw::OF_MESH_NORMALS;
         if (attr) sp.flags |= fw::OF_MESH_ATTR;
         return FW_OK;
@@ -498,7 +792,8 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     }
     const int n_cus_dev = device < MAX_DEVICES ? cu_cache[device] : 256;
     // FIREWORK_TRACE=1: where a scene creation spends its time (host flatten + BVH builds | staging blob | alloc | copy)
-    const bool trace = getenv("FIREWORK_TRACE") != nullptr;
+    const Options O = options();
+    const bool trace = O.trace;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(now() - t).count(); };
     const auto tr0 = now();
@@ -507,6 +802,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     std::vector<float> objs((size_t)desc->n_objects * fw::OBJ_Q * 4, 0.f);
     std::vector<Box> world(desc->n_objects), true_world(desc->n_objects);
     std::vector<uint32_t> obj_ref_blas(desc->n_objects, 0xffffffffu);
+    std::vector<uint32_t> obj_wroot_f32(desc->n_objects, 0xffffffffu), obj_wroot_q8(desc->n_objects, 0xffffffffu);
     std::vector<float> obj_size(desc->n_objects, 0.f);       // the exact walk's far rule: extent of an object (a mesh: of a typical triangle)
     fw::DExact ex{};
     bool has_medium = false, has_perlin = false;
@@ -537,6 +833,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         world[i] = to_world(sp.box);
         if (flags & fw::OF_GATE) true_world[i] = to_world(sp.true_box);
         obj_ref_blas[i] = sp.ref_root;
+        if ((sp.kind & 0xffu) == FW_SHAPE_TRIANGLE_MESH) { obj_wroot_f32[i] = sp.wroot_f32; obj_wroot_q8[i] = sp.wroot_q8; }
         {
             const Box &tb = (flags & fw::OF_GATE) ? sp.true_box : sp.box;
             const V3 e = tb.mx - tb.mn;
@@ -587,21 +884,26 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
             const V3 c = box_center(cl), h = cl.mx - c;
             const float radius = std::fmax(h.x, std::fmax(h.y, h.z));
             ex.far_c[0] = c.x; ex.far_c[1] = c.y; ex.far_c[2] = c.z;
-            ex.far_r = std::fmax(1024.f * min_size, 2.f * radius);  // noise / signal of a sphere's discriminant = 2^-23 (|o| / r)^2 = 2^-23 (2 |o| / size)^2: 1/2 at this distance
+            ex.far_r = std::fmax((float)O.exact_far_x * min_size, 2.f * radius);  // noise / signal of a sphere's discriminant = 2^-23 (|o| / r)^2 = 2^-23 (2 |o| / size)^2: 1/2 at this distance
                                                                     // (128 x flagged every camera ray of teapot.rs, whose camera sits 16 units from triangles of 0.08)
             const float pad = 2.f * min_size + 1e-3f * radius;
             ex.box_lo[0] = cl.mn.x - pad; ex.box_lo[1] = cl.mn.y - pad; ex.box_lo[2] = cl.mn.z - pad;
             ex.box_hi[0] = cl.mx.x + pad; ex.box_hi[1] = cl.mx.y + pad; ex.box_hi[2] = cl.mx.z + pad;
             ex.mode |= 2u;                                          // used under use_bvh only (render_impl)
         }
-        if (getenv("FIREWORK_NO_EXACT")) ex.mode = 0;
-        if (const char *e = getenv("FIREWORK_EXACT_ALL")) { if (atoi(e)) ex.mode |= 4u; }   // every ray takes the exact walk (parity tool / tests)
+        ex.shear = std::ldexp(1.f, -O.exact_shear_log2);
+        if (O.no_exact) ex.mode = 0;
+        if (O.exact_all) ex.mode |= 4u;   // every ray takes the exact walk (parity tool / tests)
     }
     // gate boxes: the box of each object's leaf node in the reference tree (own box for a Leaf, the union for a
     // DoubleLeaf).  In the reference an object is tested iff the ray hits that box (ancestors are supersets), which
     // matters for shapes whose own box does not enclose them (OF_GATE): they stay exactly as (in)visible as there.
+    // Round 4: the reference tests an object iff the ray passes the box of its LEAF NODE in the reference tree (the union for a
+    // DoubleLeaf: bvh.rs:44-52; the ancestors' boxes are supersets).  The walked trees keep the objects' own boxes (the unions cost
+    // part2 26 %: gpurun_out/r04d); every object hit is checked against its reference leaf-node box (obj_gate) before it counts, and
+    // a mesh before its rays are parked (fw_kernels.hip: obj_gate_ok).
     std::vector<float> gate((size_t)desc->n_objects * 8, 0.f);
-    std::vector<Box> build_boxes = world;
+    std::vector<Box> build_boxes = world, own_boxes = world;
     for (uint32_t i = 0; i < tlas.count(); i++) {
         const float *nd = &tlas.nodes[(size_t)i * 8];
         uint32_t A, B; std::memcpy(&A, nd + 3, 4); std::memcpy(&B, nd + 7, 4);
@@ -612,23 +914,29 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
             float *g = &gate[(size_t)items[q] * 8];
             g[0] = nd[0]; g[1] = nd[1]; g[2] = nd[2]; g[4] = nd[4]; g[5] = nd[5]; g[6] = nd[6];
             uint32_t kf; std::memcpy(&kf, &objs[(size_t)items[q] * fw::OBJ_Q * 4 + 3], 4);
-            // walked-tree box of a gated object: its gate box (so the gate test is reachable) united with bounds that
-            // really enclose the geometry (so culling against the best t so far stays valid)
-            if ((kf >> 8) & fw::OF_GATE) build_boxes[items[q]] = box_union(Box{{nd[0], nd[1], nd[2]}, {nd[4], nd[5], nd[6]}}, true_world[items[q]]);
+            const Box node_box{{nd[0], nd[1], nd[2]}, {nd[4], nd[5], nd[6]}};
+            // a gated object (its own box does not enclose it): the leaf node's box (so the gate test is reachable) united with bounds
+            // that really enclose the geometry (so culling against the best t so far stays valid)
+            if ((kf >> 8) & fw::OF_GATE) build_boxes[items[q]] = own_boxes[items[q]] = box_union(node_box, true_world[items[q]]);
         }
     }
-    std::vector<float> cull((size_t)desc->n_objects * 8, 0.f);       // enclosing world boxes for the camera-ray pre-test (k_extend_linear)
-    for (uint32_t i = 0; i < desc->n_objects; i++) {
-        const Box &b = build_boxes[i];
-        float *c = &cull[(size_t)i * 8];
-        c[0] = b.mn.x; c[1] = b.mn.y; c[2] = b.mn.z; c[4] = b.mx.x; c[5] = b.mx.y; c[6] = b.mx.z;
-    }
+    auto pack_boxes = [&](const std::vector<Box> &bs) {
+        std::vector<float> out((size_t)desc->n_objects * 8, 0.f);
+        for (uint32_t i = 0; i < desc->n_objects; i++) {
+            const Box &b = bs[i];
+            float *c = &out[(size_t)i * 8];
+            c[0] = b.mn.x; c[1] = b.mn.y; c[2] = b.mn.z; c[4] = b.mx.x; c[5] = b.mx.y; c[6] = b.mx.z;
+        }
+        return out;
+    };
+    const std::vector<float> cull = pack_boxes(own_boxes);       // enclosing world boxes of the objects themselves: the pre-tests of the linear scan (k_extend_linear*)
+    const std::vector<float> leafb = pack_boxes(build_boxes);    // the objects' boxes in the walked trees (k_extend_scan, hoisted_hits)
     // Hoisting: an object whose box covers most of the scene (part2's r = 5000 fog medium) is met by nearly every ray, so in
     // the tree its leaf is one more divergent leaf test per ray.  Scenes without meshes and too many objects for the scan keep
     // such objects out of the WALKED tree; the kernels test them for every ray before the walk, with a wave-uniform index
     // (hoisted_hits in fw_kernels.hip: same own-box test, same tie rule, so the same result as the leaf would give).
     std::vector<uint32_t> hoisted;
-    if (use_sah() && desc->n_objects > 8 && fl.tri.empty() && getenv("FIREWORK_NO_HOIST") == nullptr) {
+    if (use_sah() && desc->n_objects > 8 && fl.tri.empty() && !O.no_hoist) {
         Box root = build_boxes[0];
         for (const Box &b : build_boxes) root = box_union(root, b);
         const float ra = box_area(root);
@@ -656,6 +964,25 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     }
     PairBvh tlas_p;
     const uint32_t tlas_root = pair_convert(tlas, build_boxes, tlas_p);
+    // WIDE nodes (fw_device.h) for the LDS-resident walks, where they fit a CU's LDS next to the walks' stacks: f32 nodes first,
+    // quantised ones for a BLAS too big for those.  Option WIDE=0: none (the pair-node kernels, A/B); =f32 / =q8 force an encoding.
+    const bool wide_on = use_sah() && O.wide != 0;
+    WideBvh wtlas; wtlas.fmt = fw::WIDE_F32;
+    uint32_t wtlas_root = 0xffffffffu;
+    auto wide_lds_bytes = [&](const WideBvh &t, uint32_t waves) { return (size_t)t.words.size() * 4 + (size_t)waves * (3 * t.depth + 2) * 128 + 4096; };
+    if (wide_on && fl.tri.empty() && desc->n_objects > 8) {
+        wtlas_root = wide_convert(tlas, build_boxes, wtlas);     // (hoisted objects are not in `tlas`; its leaves hold object ids)
+        if (wtlas_root == 0xffffffffu || wide_lds_bytes(wtlas, 8) > fw::LDS_TREE_LIMIT) { wtlas.words.clear(); wtlas_root = 0xffffffffu; }
+    }
+    int wblas_fmt = fw::WIDE_NONE;
+    if (wide_on && !fl.tri.empty()) {
+        const bool force_q8 = O.wide == 2, force_f32 = O.wide == 1;
+        if (fl.wide_ok[0] && !force_q8 && wide_lds_bytes(fl.wblas_f32, 8) <= fw::LDS_TREE_LIMIT) wblas_fmt = fw::WIDE_F32;
+        else if (fl.wide_ok[1] && !force_f32 && wide_lds_bytes(fl.wblas_q8, 8) <= fw::LDS_TREE_LIMIT) wblas_fmt = fw::WIDE_Q8;
+    }
+    const WideBvh &wblas = wblas_fmt == fw::WIDE_Q8 ? fl.wblas_q8 : fl.wblas_f32;
+    std::vector<uint32_t> obj_wroot(desc->n_objects, fw::W_DONE);
+    for (uint32_t i = 0; i < desc->n_objects; i++) obj_wroot[i] = wblas_fmt == fw::WIDE_Q8 ? obj_wroot_q8[i] : obj_wroot_f32[i];
 
     // materials / textures / images
     std::vector<float> mats((size_t)std::max(1u, desc->n_materials) * 8, 0.f), texs((size_t)std::max(1u, desc->n_textures) * 8, 0.f);
@@ -711,6 +1038,7 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
                 if (c.kind == FW_TEX_CHECKER) { todo.push_back(c.odd); todo.push_back(c.even); }
             }
         }
+        if (m.kind == FW_MAT_DIELECTRIC) { q[4] = q[5] = q[6] = 1.f; }          // its attenuation (material.rs:128), for the chain state's product
         q[0] = bits_f(mbits); q[1] = bits_f((uint32_t)(needs_tex ? m.texture : 0)); q[2] = m.roughness; q[3] = m.ref_idx;
     }
     const fw_environment &e = desc->environment;
@@ -728,14 +1056,17 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     // one device allocation + one copy for the whole scene (12 separate hipMalloc/hipFree pairs cost up to 30 ms of a
     // one-shot render): sections are 256-byte aligned inside a host staging blob
     struct Sec { const void *src; size_t bytes, off; };
-    Sec secs[16] = {
+    Sec secs[21] = {
         {objs.data(), objs.size() * 4, 0}, {tlas_p.nodes.data(), tlas_p.nodes.size() * 4, 0}, {fl.blas.nodes.data(), fl.blas.nodes.size() * 4, 0},
         {fl.tri.data(), fl.tri.size() * 4, 0}, {fl.any_attr ? fl.tri_attr.data() : nullptr, fl.any_attr ? fl.tri_attr.size() * 4 : 0, 0},
         {fl.tri_rank.data(), fl.tri_rank.size() * 4, 0}, {obj_rank.data(), obj_rank.size() * 4, 0}, {gate.data(), gate.size() * 4, 0},
         {mats.data(), mats.size() * 4, 0}, {texs.data(), texs.size() * 4, 0}, {images.data(), images.size(), 0},
         {e.kind == FW_ENV_HDR ? e.hdr_rgb : nullptr, e.kind == FW_ENV_HDR ? (size_t)e.hdr_w * e.hdr_h * 3 * 4 : 0, 0},
         {cull.data(), cull.size() * 4, 0},
-        {ref_tlas.data(), ref_tlas.size() * 4, 0}, {fl.ref_blas.data(), fl.ref_blas.size() * 4, 0}, {obj_ref_blas.data(), obj_ref_blas.size() * 4, 0}};
+        {ref_tlas.data(), ref_tlas.size() * 4, 0}, {fl.ref_blas.data(), fl.ref_blas.size() * 4, 0}, {obj_ref_blas.data(), obj_ref_blas.size() * 4, 0},
+        {leafb.data(), leafb.size() * 4, 0},
+        {wblas_fmt ? wblas.words.data() : nullptr, wblas_fmt ? wblas.words.size() * 4 : 0, 0}, {wtlas.words.data(), wtlas.words.size() * 4, 0},
+        {obj_wroot.data(), obj_wroot.size() * 4, 0}, {fl.tri_gate.data(), fl.tri_gate.size() * 4, 0}};
     size_t total = 0;
     for (Sec &x : secs) { x.off = total; total += (x.bytes + 255) & ~(size_t)255; }
     total = std::max<size_t>(total, 256);                  // a multiple of 256: k_upload copies 16-byte words
@@ -788,9 +1119,19 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     d.obj_cull = (const float4 *)(base + secs[12].off);
     d.ref_tlas = (const float4 *)(base + secs[13].off); d.ref_blas = (const float4 *)(base + secs[14].off);
     d.obj_ref_blas = (const uint32_t *)(base + secs[15].off);
+    d.obj_leaf = (const float4 *)(base + secs[16].off);
+    d.wblas = wblas_fmt ? (const uint32_t *)(base + secs[17].off) : nullptr;
+    d.wtlas = wtlas.words.empty() ? nullptr : (const uint32_t *)(base + secs[18].off);
+    d.obj_wroot = (const uint32_t *)(base + secs[19].off);
+    d.tri_gate = (const float4 *)(base + secs[20].off);
+    d.wtlas_root = wtlas_root;
+    sc->wblas_fmt = wblas_fmt; sc->wtlas_fmt = wtlas.words.empty() ? fw::WIDE_NONE : fw::WIDE_F32;
+    sc->wblas_nodes = wblas_fmt ? wblas.count() : 0; sc->wtlas_nodes = wtlas.count();
+    sc->wblas_depth = wblas_fmt ? wblas.depth : 0; sc->wtlas_depth = wtlas.depth;
     sc->ex = ex; sc->ref_tlas_depth = ref_tlas_depth; sc->ref_blas_depth = fl.ref_blas_depth;
     d.n_objects = desc->n_objects; d.has_medium = has_medium ? 1u : 0u; d.has_perlin = has_perlin ? 1u : 0u; d.has_mesh = fl.tri.empty() ? 0u : 1u;
     d.prim_bits = prim_bits; d.tlas_root = tlas_root;
+    d.soft_shear = O.soft_shear_log2 > 0 ? std::ldexp(1.f, -O.soft_shear_log2) : 0.f;
     d.n_hoisted = (uint32_t)hoisted.size();
     for (size_t i = 0; i < 4; i++) d.hoisted[i] = i < hoisted.size() ? hoisted[i] : 0u;
     d.env.kind = e.kind;
@@ -804,6 +1145,18 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         uint32_t mb; std::memcpy(&mb, &mats[(size_t)i * 8], 4);
         const uint32_t mk = mb & 0xffu;
         if (mk == (uint32_t)FW_MAT_DIELECTRIC || (!(mb & fw::MF_TEX_CONST) && (mk == (uint32_t)FW_MAT_LAMBERTIAN || mk == (uint32_t)FW_MAT_EMISSIVE || mk == (uint32_t)FW_MAT_ISOTROPIC))) sc->has_expensive = true;
+    }
+    // chain state (fw_kernels.hip: load_state_chain): every attenuation a constant of its material, and ten material ids in 32 bits
+    sc->chain_bits = 0;
+    {
+        bool constant = desc->n_materials > 0;
+        for (uint32_t i = 0; i < desc->n_materials; i++) {
+            uint32_t mb; std::memcpy(&mb, &mats[(size_t)i * 8], 4);
+            const uint32_t mk = mb & 0xffu;
+            if (!(mb & fw::MF_TEX_CONST) && (mk == (uint32_t)FW_MAT_LAMBERTIAN || mk == (uint32_t)FW_MAT_EMISSIVE || mk == (uint32_t)FW_MAT_ISOTROPIC)) constant = false;
+        }
+        uint32_t bits = 1; while ((1u << bits) < desc->n_materials) bits++;
+        if (constant && 10u * bits <= 32u) sc->chain_bits = bits;
     }
     sc->simple_shapes = true;
     for (uint32_t i = 0; i < desc->n_objects; i++) { uint32_t kf; std::memcpy(&kf, &objs[(size_t)i * fw::OBJ_Q * 4 + 3], 4); if ((kf & 0xffu) > 4u) sc->simple_shapes = false; }
@@ -846,8 +1199,8 @@ fw::DCamera make_camera(const fw_camera_settings &s, uint32_t width, uint32_t he
 // (measured on cornell 512x512@1024: 4 Mi paths 85 ms/frame, 16 Mi 64 ms, 256 Mi = the whole frame 55 ms).
 // Default: up to 2^28 paths (104 B per slot + 40 B for parked mesh rays, and up to twice as many slots as paths because a
 // wave's queue capacity is a power of two: 28-77 GB), never more than half of the free HBM.
-uint32_t default_paths_per_batch() {
-    if (const char *e = getenv("FIREWORK_PATHS_PER_BATCH")) { long long v = atoll(e); if (v > 0) return (uint32_t)std::min<long long>(v, 0x7fffffffll); }
+uint32_t default_paths_per_batch(const Options &O) {
+    if (O.paths_per_batch > 0) return (uint32_t)std::min<long long>(O.paths_per_batch, 0x7fffffffll);
     size_t free_b = 0, total_b = 0;
     uint64_t budget = 1ull << 28;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, (uint64_t)(free_b / 2) / 288u);
@@ -873,6 +1226,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     Workspace *ws = workspace_for(sc->device);
     if (!ws) return fail(FW_ERR_OOM, "no workspace for this device");
     std::lock_guard<std::mutex> ws_guard(ws->mu);
+    const Options O = options();
 
     // ---- batches and lanes -----------------------------------------------------------------------------------
     // Two batches in flight on two streams under use_bvh: the tree walks leave issue slots and HBM idle (the LDS-resident
@@ -886,9 +1240,9 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // the roofline come from an exclusive pass (FIREWORK_STREAMS=1) that bench.py runs next to the timed loop.
     // (Small frames too: random_spheres, 5.8 M paths, 1.83 ms in two batches against 1.92-1.97 in one, round 3.)
     int n_lanes = (p->use_bvh || sc->n_defer > 0) ? 2 : 1;
-    if (const char *e = getenv("FIREWORK_STREAMS")) { int v = atoi(e); if (v >= 1) n_lanes = std::min(v, (int)Workspace::MAX_LANES); }
+    if (O.streams >= 1) n_lanes = std::min(O.streams, (int)Workspace::MAX_LANES);
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, p->samples);
-    uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch() / (uint32_t)n_lanes;
+    uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch(O) / (uint32_t)n_lanes;
     uint32_t spp_b = std::max<uint32_t>(1u, budget / n_pix);
     spp_b = std::min(spp_b, (p->samples + (uint32_t)n_lanes - 1) / (uint32_t)n_lanes);     // at least one batch per lane
     uint64_t paths64 = (uint64_t)n_pix * spp_b;
@@ -906,7 +1260,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     const uint32_t unit = (uint32_t)sc->n_cus * 4u * (p->use_bvh ? 20u : 28u);
     const uint64_t chunks = ((uint64_t)max_paths + 63u) / 64u;
     uint32_t want_waves = unit * (uint32_t)std::min<uint64_t>(3u, std::max<uint64_t>(1u, chunks / ((uint64_t)unit * 16u)));
-    if (const char *e = getenv("FIREWORK_WAVES")) { long v = atol(e); if (v > 0) want_waves = (uint32_t)v; }
+    if (O.waves > 0) want_waves = (uint32_t)O.waves;
     q.n_waves = std::max(4u, std::min(want_waves, (max_paths + 511u) / 512u));
     q.n_waves = (q.n_waves + 3u) & ~3u;
     uint32_t chunks_per_wave = (max_paths + q.n_waves * 64u - 1) / (q.n_waves * 64u);
@@ -920,9 +1274,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // the exact walk: ill-conditioned mesh rays in any mode, far origins and "every ray" (FIREWORK_EXACT_ALL) under use_bvh only
     // (the linear scan tests every object anyway: only a mesh's BLAS is walked there)
     // (FIREWORK_FUSED=1, the one-launch-per-segment A/B kernel, has no second pass: it runs without the exact walk)
-    const bool fused_req = [] { const char *fe = getenv("FIREWORK_FUSED"); return fe && atoi(fe) != 0; }() && !(p->use_bvh && sc->d.has_mesh);
+#if FW_AB
+    const bool fused_req = O.fused && !(p->use_bvh && sc->d.has_mesh);
+    const bool tlas_refill = !O.tlas_refill_off;
+#else
+    const bool fused_req = false, tlas_refill = true;
+#endif
     const uint32_t exact_mode = fused_req ? 0u : ((sc->ex.mode & 1u) | (p->use_bvh ? (sc->ex.mode & 6u) : ((sc->ex.mode & 4u) && sc->d.has_mesh ? 4u : 0u)));
-    const bool tlas_refill = [] { const char *tr = getenv("FIREWORK_TLAS_REFILL"); return !(tr && atoi(tr) == 0); }();
     const bool park_meshes = p->use_bvh && sc->d.has_mesh != 0 && tlas_refill;
     int rc = FW_OK;
     auto need = [&](DevBuf &b, size_t n) { if (!rc) rc = b.alloc(n); };
@@ -945,7 +1303,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     if (p->pixel_ids) need(ws->pixel_ids, (size_t)n_pix * 4);
     // a whole frame is traced in the library's own 16x16-tile order (k_tile_order); k_resolve undoes it.  Not for progressive
     // renders: their accumulation buffer belongs to the caller and stays in pixel order.
-    const bool own_order = !p->pixel_ids && !user_accum && n_pix >= 1024 && getenv("FIREWORK_NO_TILE_ORDER") == nullptr;
+    const bool own_order = !p->pixel_ids && !user_accum && n_pix >= 1024 && !O.no_tile_order;
     if (own_order) { const void *before = ws->tile_ids.p; need(ws->tile_ids, (size_t)n_pix * 4); if (ws->tile_ids.p != before) ws->tile_w = ws->tile_h = 0; }
     uint8_t *d_rgb8 = rgb8; float *d_gamma = gamma_rgb, *d_linear = linear_rgb;
     if (!p->outputs_on_device) {
@@ -975,21 +1333,26 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.blocks_other = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_pix + fw::BLOCK - 1) / fw::BLOCK, (uint64_t)max_blocks));
     cfg.tlas_depth = (int)sc->tlas_depth; cfg.blas_depth = (int)sc->blas_depth;
     cfg.n_mat = sc->n_mat; cfg.n_tex = sc->n_tex;
-    cfg.lds_tables = getenv("FIREWORK_NO_LDS_TABLES") == nullptr;
+    cfg.lds_tables = !O.no_lds_tables;
     cfg.has_mesh = sc->d.has_mesh != 0;
     cfg.tlas_refill = tlas_refill;
     cfg.n_cus = sc->n_cus;
     cfg.blas_pair_nodes = sc->blas_pair_nodes; cfg.tlas_pair_nodes = sc->tlas_pair_nodes; cfg.max_tris = sc->max_tris; cfg.n_tris = sc->n_tris;
-    cfg.no_lds_tris = getenv("FIREWORK_NO_LDS_TRIS") != nullptr;
-    cfg.n_defer = (!p->use_bvh && getenv("FIREWORK_NO_DEFER") == nullptr) ? sc->n_defer : 0u;
-    cfg.lds_trees = getenv("FIREWORK_NO_LDS_TREES") == nullptr;
-    { const char *ef = getenv("FIREWORK_EXACT_FORM"); cfg.exact_form = ef ? (strcmp(ef, "lane") == 0 ? 1 : (strcmp(ef, "wave") == 0 ? 2 : 0)) : 0; }
+    cfg.no_lds_tris = O.no_lds_tris;
+    cfg.n_defer = (!p->use_bvh && !O.no_defer) ? sc->n_defer : 0u;
+    cfg.lds_trees = !O.no_lds_trees;
+    cfg.wblas_fmt = sc->wblas_fmt; cfg.wtlas_fmt = sc->wtlas_fmt; cfg.wblas_nodes = sc->wblas_nodes; cfg.wtlas_nodes = sc->wtlas_nodes;
+    cfg.wblas_depth = sc->wblas_depth; cfg.wtlas_depth = sc->wtlas_depth;
+    cfg.exact_form = O.exact_form;
     cfg.ref_tlas_nodes = sc->tlas_nodes; cfg.ref_blas_nodes = sc->blas_nodes; cfg.ref_tlas_depth = sc->ref_tlas_depth; cfg.ref_blas_depth = sc->ref_blas_depth;
     // k_shade's list entries are 16-bit queue positions: longer queues (cap > 65536: never with the default geometry) shade in line
     // Default: the cheap loop alone where the scene has nothing expensive (cornell k_shade -5 %), everything in line otherwise — the
     // list (mode 2) is slower wherever it was measured (gpurun_out/r03h: part2@16 11.7 -> 12.0 ms, hdri@64 5.5 -> 6.1, random_spheres
     // 1.90 -> 1.98, volume@64 6.08 -> 6.12) and stays behind FIREWORK_SHADE_LIST=1; FIREWORK_NO_SHADE_DEFER=1 forces mode 0.
-    cfg.shade_mode = getenv("FIREWORK_NO_SHADE_DEFER") != nullptr ? 0 : (!sc->has_expensive ? 1 : ((getenv("FIREWORK_SHADE_LIST") != nullptr && q.cap <= 65536u) ? 2 : 0));
+    cfg.shade_mode = !sc->has_expensive ? 1 : 0;
+#if FW_AB
+    if (O.no_shade_defer) cfg.shade_mode = 0; else if (sc->has_expensive && O.shade_list && q.cap <= 65536u) cfg.shade_mode = 2;
+#endif
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
     fw::DFrame fr;
@@ -1000,14 +1363,15 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     fr.q_n_waves = q.n_waves; fr.q_shift = q.cpw_shift;
     fr.cam_pos[0] = cam.position[0]; fr.cam_pos[1] = cam.position[1]; fr.cam_pos[2] = cam.position[2];
     fr.pinhole0 = (cam.lens_radius == 0.f && cam.position[0] != 0.f && cam.position[1] != 0.f && cam.position[2] != 0.f &&
-                   getenv("FIREWORK_NO_SHORT_RAYS") == nullptr) ? 1u : 0u;
+                   !O.no_short_rays) ? 1u : 0u;
     // 4-byte hit records where k_shade can recompute t cheaply and exactly: the linear scan over spheres, rects and Rect3d
-    fr.hit4 = (!p->use_bvh && sc->simple_shapes && !exact_mode && getenv("FIREWORK_NO_HIT4") == nullptr && !(getenv("FIREWORK_FUSED") && atoi(getenv("FIREWORK_FUSED")))) ? 1u : 0u;
+    fr.hit4 = (!p->use_bvh && sc->simple_shapes && !exact_mode && !O.no_hit4 && !fused_req) ? 1u : 0u;
     const fw::DEnv &env = sc->d.env;
     // (pixel-major bits need the sample index of a path from a float quotient that is exact only while spp_batch < 2^21: dep_bit_of)
-    fr.dep_pixel_major = (((n_pix <= 65536u && getenv("FIREWORK_DEP_SLOT_MAJOR") == nullptr) || getenv("FIREWORK_DEP_PIXEL_MAJOR") != nullptr) && spp_b < (1u << 21)) ? 1u : 0u;
+    fr.dep_pixel_major = (((n_pix <= 65536u && !O.dep_slot_major) || O.dep_pixel_major) && spp_b < (1u << 21)) ? 1u : 0u;
     fr.ex = sc->ex; fr.ex.mode = exact_mode;
-    fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && getenv("FIREWORK_NO_ZERO_SKIP") == nullptr) ? 1u : 0u;
+    fr.chain_bits = (O.no_chain || fused_req) ? 0u : sc->chain_bits;
+    fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && !O.no_zero_skip) ? 1u : 0u;
 
     // per-launch timing (FW_FLAG_TIME_KERNELS): one event after every launch on the launch's own stream; the end of
     // launch k is the start of launch k+1 of that lane.  With several lanes the intervals overlap in wall time.
@@ -1026,13 +1390,17 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // Off by default: the frame is VALU-bound, not HBM-bound, and the fused kernel's lower occupancy costs more than the
     // bytes save (cornell 62.0 vs 55.5 ms, hdri 35.5 vs 38.5 ms, 1/8-frame shares 9.2 vs 8.3 ms).  Never with parked mesh rays.
     const bool fused = fused_req;
-    const bool stagger = n_lanes > 1 && getenv("FIREWORK_STAGGER") != nullptr;   // experiment: batch b's first k_extend waits for batch b-1's
+#if FW_AB
+    const bool stagger = n_lanes > 1 && O.stagger;   // experiment: batch b's first k_extend waits for batch b-1's
+#else
+    const bool stagger = false;
+#endif
 
     // FIREWORK_DUMP_PATH=file, one pixel x one sample: after every k_extend the path's ray, state and hit record are copied out
     // and written to `file` as 11 x 16 floats (ray_a[4] ray_b[2] state[4] hit[2] alive pad[3]) behind a header of 8 u32
     // (magic, pinhole0, hit4, prim_bits, bits of cam_pos[3], n_defer).  Debug aid of tools/diverge.py; never on a timed path.
-    const char *dump_file = getenv("FIREWORK_DUMP_PATH");
-    const bool dump_one = dump_file && *dump_file && n_pix == 1 && p->samples == 1 && !fused;
+    const char *dump_file = O.dump_path.c_str();
+    const bool dump_one = *dump_file && n_pix == 1 && p->samples == 1 && !fused;
     std::vector<float> dump_rec(dump_one ? (size_t)fw::MAX_SEGMENTS * 16 : 0, 0.f);
 
     HIPCHK(hipEventRecord(ws->events[0], stream));
@@ -1072,8 +1440,11 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         int cur = 0;
         timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], srad, n_paths); });
         for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
+#if FW_AB
             if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
-            else {
+            else
+#endif
+            {
                 if (stagger && seg == 0 && b > 0) HIPCHK(hipStreamWaitEvent(ls, ws->events[3 + n_batches + b - 1], 0));   // start half a segment behind the batch before
                 timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park); });
                 if (stagger && seg == 0) HIPCHK(hipEventRecord(ws->events[3 + n_batches + b], ls));
@@ -1116,7 +1487,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             fwrite(hdr, 4, 8, fp); fwrite(dump_rec.data(), 4, dump_rec.size(), fp); fclose(fp);
         }
     }
-    const bool trace = getenv("FIREWORK_TRACE") != nullptr;
+    const bool trace = O.trace;
     const auto tq0 = std::chrono::steady_clock::now();
     auto since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
     // Device -> host through PINNED memory, then a host memcpy into the caller's buffers.  A hipMemcpyAsync into pageable
@@ -1173,7 +1544,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             for (int s = 1; s < fw::MAX_SEGMENTS; s++) { rd_ray += R[s] * fw::B_RAY; later += R[s]; survivors += R[s]; }
             stats->bytes_raygen = S * ray0 + (fr.pixel_ids ? S * 4 : 0);
             const uint64_t medium = sc->d.has_medium ? later * 4 : 0;       // the path's home slot (RNG key of the medium's draw)
-            const uint64_t shade_in = rd_ray + later * fw::B_STATE, shade_out = survivors * (fw::B_RAY + fw::B_STATE) + stats->deposits * fw::B_DEPOSIT;
+            const uint64_t b_state = fr.chain_bits ? fw::B_STATE_CHAIN : fw::B_STATE;
+            const uint64_t shade_in = rd_ray + later * b_state, shade_out = survivors * (fw::B_RAY + b_state) + stats->deposits * fw::B_DEPOSIT;
             if (fused) { stats->bytes_extend = 0; stats->bytes_shade = shade_in + shade_out; }
             else {
                 stats->bytes_extend = rd_ray + medium + stats->rays * b_hit + stats->parked_rays * 2 * fw::B_PARK;
@@ -1277,6 +1649,37 @@ int fw_selftest_libm(int device, int fn, uint32_t n, const float *x, const float
     if (e != hipSuccess) return fail(FW_ERR_HIP, hipGetErrorString(e));
     return FW_OK;
 }
+
+int fw_set_option(const char *name, const char *value) {
+    std::lock_guard<std::mutex> g(g_opt_mu);
+    if (!name) { g_opt = options_from_env(); return FW_OK; }          // back to what the environment said
+    const char *n = std::strncmp(name, "FIREWORK_", 9) == 0 ? name + 9 : name;
+    if (!option_apply(g_opt, n, value)) return fail(FW_ERR_BAD_ARG, std::string("unknown option ") + name);
+    return FW_OK;
+}
+
+// CPU-only diagnostic: the WIDE-node builder (wide_convert) on a caller's item boxes, its invariants checked on the finished tree
+// (every item exactly once, every decoded child box a superset of the exact one, free slots unhittable, f32 item boxes bit for bit).
+// boxes: n x 6 floats (min.xyz max.xyz); format: FW_WIDE_F32 (1) or FW_WIDE_Q8 (2); stats: nodes, leaves, free slots, depth.
+int fw_selftest_wide_bvh(const float *boxes, uint32_t n, int format, uint32_t *violations, uint32_t stats[4]) {
+    if (!boxes || n == 0 || !violations || !stats || (format != fw::WIDE_F32 && format != fw::WIDE_Q8)) return fail(FW_ERR_BAD_ARG, "bad argument");
+    try {
+        std::vector<Box> b(n);
+        for (uint32_t i = 0; i < n; i++) b[i] = Box{{boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]}, {boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5]}};
+        FlatBvh sah; sah_build(sah, b);
+        WideBvh w; w.fmt = format;
+        const uint32_t root = wide_convert(sah, b, w);
+        if (root == 0xffffffffu) return fail(FW_ERR_UNSUPPORTED, "tree not encodable as wide nodes (more than 32767 items or nodes, or a box that is not finite)");
+        *violations = wide_check(w, root, b, stats);
+        return FW_OK;
+    }
+    catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
+    catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_selftest_wide_bvh"); }
+}
+
+#if FW_AB
+int fw_debug_ab(void) { return 1; }      // present only in the A/B build: tests of the alternative kernels look for it
+#endif
 
 int fw_scene_create(const fw_scene_desc *desc, int device, fw_scene **out) {
     try { return create_scene_impl(desc, device, out); }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 5   /* 3: + fw_render_progressive; 4: fw_stats carries this layout's own HBM bytes per kernel class and the one-shot timings;
+#define FW_ABI_VERSION 6   /* 6: + fw_set_option (the runtime switches leave the environment: read once at load), fw_selftest_wide_bvh; 3: + fw_render_progressive; 4: fw_stats carries this layout's own HBM bytes per kernel class and the one-shot timings;
                               5: + fw_selftest_libm; the 4th float of an accumulation record counts the path segments of the samples that deposited */
 
 /* ---- status codes ------------------------------------------------------ */
@@ -293,6 +293,28 @@ int fw_selftest_arith(int device, uint32_t n, uint32_t seed, int mode, uint64_t 
    fn: 0 logf  1 log10f  2 sinf  3 asinf  4 acosf  5 atanf  6 atan2f(x[i], y[i]) = atan2(first, second)  7 powf(x[i], y[i]).
    y may be NULL for the one-argument functions.  tests/test_gpu_libm.py compares the results with the host's libm bit for bit. */
 int fw_selftest_libm(int device, int fn, uint32_t n, const float *x, const float *y, float *out);
+
+/* Runtime options.  The library reads the environment variables FIREWORK_<NAME> ONCE, when it is loaded; nothing on the render path
+   looks at the environment.  fw_set_option changes one option afterwards (name with or without the FIREWORK_ prefix; value NULL =
+   back to the default; name NULL = back to what the environment said at load time) and applies to the scenes created and the renders
+   started after it returns.  Results never depend on an option — only which kernels produce them (every pair of settings is
+   compared bit for bit in tests/) — except the diagnostics NO_EXACT / EXACT_ALL.  Names:
+     BVH=median            walk the reference's own median-split topology instead of the SAH tree (parity / A-B mode)
+     WIDE=0|f32|q8         no wide nodes (the pair-node kernels) / force an encoding of the wide nodes
+     EXACT_ALL=1, NO_EXACT, EXACT_FORM=lane|wave      every ray / no ray through the literal reference walk; its form
+     STREAMS=n, WAVES=n, PATHS_PER_BATCH=n            batches in flight, wave queues, pool size
+     NO_DEFER NO_HIT4 NO_HOIST NO_LDS_TABLES NO_LDS_TREES NO_LDS_TRIS NO_SHORT_RAYS NO_TILE_ORDER NO_ZERO_SKIP
+     DEP_PIXEL_MAJOR DEP_SLOT_MAJOR NO_CHAIN          the layout choices the tests force both ways
+     TRACE, DUMP_PATH=file                            host-side timing trace; one path's records (tools/diverge.py)
+   Returns FW_ERR_BAD_ARG for a name this build does not know. */
+int fw_set_option(const char *name, const char *value);
+
+/* Diagnostic, CPU only: builds the WIDE nodes the LDS-resident walks step through (four children per node; format 1 = f32 planes,
+   2 = planes quantised to 8 bits and rounded outward) over n item boxes (n x 6 floats: min.xyz max.xyz) and checks the finished
+   tree: every item the leaf of exactly one slot, every child box as the device decodes it a superset of the exact one (f32: the
+   item's own box bit for bit), free slots unhittable.  violations = 0 is the only acceptable answer; stats = nodes, leaves,
+   free slots, depth. */
+int fw_selftest_wide_bvh(const float *boxes, uint32_t n, int format, uint32_t *violations, uint32_t stats[4]);
 
 #ifdef __cplusplus
 }

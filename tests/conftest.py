@@ -43,3 +43,38 @@ def block_means(img, rows, cols):
     bh, bw = h // rows, w // cols
     return np.array([[img[r * bh:(r + 1) * bh, c * bw:(c + 1) * bw].reshape(-1, 3).mean(0) for c in range(cols)]
                      for r in range(rows)])
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """The library reads FIREWORK_* from the environment once, when it is loaded; afterwards a switch is changed through
+    fw_set_option.  Tests keep writing monkeypatch.setenv / delenv: this wrapper passes every FIREWORK_* name on to the loaded
+    library as well (child processes still see the environment) and restores the defaults after the test."""
+    from firework_amd import _lib
+    process_only = {"FIREWORK_LIB", "FIREWORK_NO_TORCH"}
+    touched = {}
+    orig_set, orig_del = monkeypatch.setenv, monkeypatch.delenv
+
+    def push(name, value, before):
+        if name.startswith("FIREWORK_") and name not in process_only and os.path.exists(_lib.LIB_PATH):
+            try:
+                _lib.set_option(name, value)
+                touched.setdefault(name, before)
+            except _lib.FireworkError:
+                if value is not None:
+                    pytest.skip(f"{name} is a switch of the A/B build (make ab; FIREWORK_LIB=firework_amd/lib/variants/lib_ab.so)")
+
+    def setenv(name, value, prepend=None):
+        before = os.environ.get(name)
+        orig_set(name, value, prepend)
+        push(name, str(value), before)
+
+    def delenv(name, raising=True):
+        before = os.environ.get(name)
+        orig_del(name, raising)
+        push(name, None, before)
+
+    monkeypatch.setenv, monkeypatch.delenv = setenv, delenv
+    yield monkeypatch
+    for name, before in touched.items():
+        _lib.set_option(name, before)

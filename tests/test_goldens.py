@@ -37,5 +37,5 @@ def test_gpu_matches_goldens(name):
     gam = lambda lin: np.clip(np.clip(np.nan_to_num(lin, nan=0.0), 0, None) ** (1 / 2.2), 0, 1)
     rms = float(np.sqrt(np.mean((gam(res.linear.astype(np.float64)) - gam(g["linear"].astype(np.float64))) ** 2)))
     assert rms <= 1e-3, rms                                                   # north-star gate
-    assert (res.rgb8 != g["rgb8"]).sum() <= 6
-    assert abs(int(res.stats["rays"]) - int(g["rays_per_depth"].sum())) <= 40
+    assert np.array_equal(res.rgb8, g["rgb8"])                              # zero tolerance since round 4 (glibc bits + the exact walk on the device)
+    assert list(res.stats["rays_per_depth"]) == [int(x) for x in g["rays_per_depth"]]

@@ -24,7 +24,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["FIREWORK_NO_ZERO_SKIP"] = "1"        # every path deposits its length: accum.w = rays of the pixel
+os.environ["FIREWORK_NO_ZERO_SKIP"] = "1"        # every path deposits its length: accum.w = rays of the pixel (read when the library is loaded, below)
 
 import numpy as np  # noqa: E402
 
@@ -69,13 +69,13 @@ def gpu_dump(ds, renderer, pixel, sample):
     ids = np.array([pixel], np.uint32)
     fd, path = tempfile.mkstemp(suffix=".bin")
     os.close(fd)
-    os.environ["FIREWORK_DUMP_PATH"] = path
+    _lib.set_option("DUMP_PATH", path)
     try:
         accum = np.zeros((1, 4), np.float32)
         ds.render_progressive(r1, sample, accum, ids)
         raw = open(path, "rb").read()
     finally:
-        del os.environ["FIREWORK_DUMP_PATH"]
+        _lib.set_option("DUMP_PATH", None)
         os.unlink(path)
     hdr = struct.unpack("8I", raw[:32])
     cam = struct.unpack("3f", raw[16:28])
@@ -123,19 +123,27 @@ def with_env(setting):
     return k, (v or "1")
 
 
-def hunt(name, w, h, spp, max_pixels, out_path, tol):
+def hunt(name, w, h, spp, max_pixels, out_path, tol, pixels=None):
     t0 = time.time()
     scene, renderer = scenes.config(name, w, h, spp)
     sd = scene.to_desc()
     ds = _lib.DeviceScene(sd)
-    gcnt, gres = gpu_counts(ds, renderer)
-    assert int(gcnt.sum()) == int(gres.stats["rays"]), (int(gcnt.sum()), gres.stats["rays"])
-    t1 = time.time()
-    ocnt = ob.render_counts(sd, renderer).astype(np.int64)
+    if pixels:       # --pixels: the frames were compared elsewhere (tools/full_parity.py); only these pixels are searched
+        ids = np.array(pixels, np.uint32)
+        gcnt_p, gres = gpu_counts(ds, renderer, ids)
+        ocnt_p = ob.render_counts(sd, renderer, ids).astype(np.int64)
+        gcnt = np.zeros(w * h, np.int64); ocnt = np.zeros(w * h, np.int64)
+        gcnt[ids] = gcnt_p; ocnt[ids] = ocnt_p
+        t1 = time.time()
+    else:
+        gcnt, gres = gpu_counts(ds, renderer)
+        assert int(gcnt.sum()) == int(gres.stats["rays"]), (int(gcnt.sum()), gres.stats["rays"])
+        t1 = time.time()
+        ocnt = ob.render_counts(sd, renderer).astype(np.int64)
     ores = None
     report = dict(config=name, width=w, height=h, spp=spp, use_bvh=bool(renderer.settings["use_bvh"]),
                   rays_gpu=int(gcnt.sum()), rays_oracle=int(ocnt.sum()), s_gpu=round(t1 - t0, 2), s_oracle=round(time.time() - t1, 2))
-    bad = np.nonzero(gcnt != ocnt)[0]
+    bad = np.array(pixels, np.int64) if pixels else np.nonzero(gcnt != ocnt)[0]
     report["pixels_with_other_ray_count"] = [int(x) for x in bad]
     print(json.dumps(report), flush=True)
     paths = []
@@ -143,7 +151,16 @@ def hunt(name, w, h, spp, max_pixels, out_path, tol):
         ol = ob.path_lengths(sd, renderer, pix, 0, spp).astype(np.int64)
         gl = gpu_lengths(ds, renderer, pix, spp)
         assert int(gl.sum()) == int(gcnt[pix]), "one-sample renders disagree with the frame"
-        for s in [int(x) for x in np.nonzero(ol != gl)[0]]:
+        cand = [int(x) for x in np.nonzero(ol != gl)[0]]
+        if not cand and pixels:     # equal lengths but another colour: compare every sample's colour
+            r1 = clone(renderer, 1)
+            for s in range(spp):
+                accum = np.zeros((1, 4), np.float32)
+                ds.render_progressive(r1, s, accum, np.array([pix], np.uint32))
+                _, ocol = ob.trace_path(sd, renderer, pix, s)
+                if not np.allclose(np.nan_to_num(accum[0, :3].astype(np.float64)), np.nan_to_num(ocol.astype(np.float64)), rtol=1e-4, atol=1e-7):
+                    cand.append(s)
+        for s in cand:
             otr, ocol = ob.trace_path(sd, renderer, pix, s)
             entry = dict(pixel=pix, x=pix % w, row=pix // w, sample=s, len_gpu=int(gl[s]), len_oracle=int(ol[s]), switches={})
             rec, hdr, length = gpu_dump(ds, renderer, pix, s)
@@ -160,7 +177,10 @@ def hunt(name, w, h, spp, max_pixels, out_path, tol):
             # the same path under every runtime switch (scene-creation switches need a new device scene)
             for sw in SWITCHES:
                 key, val = with_env(sw)
-                os.environ[key] = val
+                try:
+                    _lib.set_option(key, val)
+                except _lib.FireworkError:
+                    continue                     # a switch of the A/B build only (make ab, FIREWORK_LIB=...lib_ab.so)
                 try:
                     ds2 = _lib.DeviceScene(sd)
                     rec2, hdr2, len2 = gpu_dump(ds2, renderer, pix, s)
@@ -168,7 +188,7 @@ def hunt(name, w, h, spp, max_pixels, out_path, tol):
                     entry["switches"][sw] = dict(len_gpu=len2, first_difference=seg2, what=why2)
                     ds2.close()
                 finally:
-                    del os.environ[key]
+                    _lib.set_option(key, None)
             # library variants (compile-time switches), each in a child process
             vdir = os.path.join(ROOT, "firework_amd", "lib", "variants")
             for vname in ("slowdiv", "nocull"):
@@ -226,5 +246,7 @@ if __name__ == "__main__":
     ap.add_argument("--max-pixels", type=int, default=6)
     ap.add_argument("--tol", type=float, default=0.0, help="also list pixels whose linear colour differs by more than tol x its magnitude")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--pixels", default=None, help="comma-separated pixel ids to search instead of comparing whole frames first")
     a = ap.parse_args()
-    hunt(a.config, a.width, a.height, a.spp, a.max_pixels, a.out, a.tol)
+    px = [int(x) for x in a.pixels.split(",")] if a.pixels else None
+    hunt(a.config, a.width, a.height, a.spp, max(a.max_pixels, len(px) if px else 0), a.out, a.tol, px)

@@ -38,11 +38,11 @@ for seed in range(first, first + count):
         sc.add_object(ro)
     cam = CameraSettings.default().cam_pos((u(-1, 1), u(1, 3), -3 * s)).look_at((0.0, s / 2, 0.0)).field_of_view(u(30, 50))
     r = Renderer.default().width(64).height(48).samples(8).use_bvh(False).camera(cam).seed(seed * 31)
-    os.environ.pop("FIREWORK_NO_DEFER", None)
+    _lib.set_option("NO_DEFER", None)
     g = r.render_full(sc)
-    os.environ["FIREWORK_NO_DEFER"] = "1"
+    _lib.set_option("NO_DEFER", "1")
     p = r.render_full(sc)
-    os.environ.pop("FIREWORK_NO_DEFER", None)
+    _lib.set_option("NO_DEFER", None)
     c = ob.render(sc, r)
     same_gpu = np.array_equal(g.linear, p.linear) and g.stats["rays_per_depth"] == p.stats["rays_per_depth"]
     scale = np.maximum(np.abs(c.linear), 1e-3)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 4: GPU suite, then the WIDE-node walks against the pair-node walks (option WIDE=0), interleaved, on the tree configs;
+# then the full-sample-count parity of the configs whose rare paths diverged in gpurun_out/r04a.
+set -o pipefail
+OUT=$PWD/gpurun_out/$1; mkdir -p $OUT
+R=$PWD
+timeout -k 10 600 python -m pytest tests -m gpu -x -q 2>&1 | tee $OUT/pytest.log | tail -8; echo "pytest rc=$?"
+run() { timeout -k 10 300 python3 $R/bench.py --steps $3 --warmup 1 --no-cpu-baseline --no-one-shot $2 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('kernel_ms_per_step',{}); print('$1', 'ms', round(d['ms_per_step'],2), 'excl', round(d['schedule']['exclusive_pass_ms_per_step'],2), 'ext', round(k.get('ms_extend',0),2), 'shd', round(k.get('ms_shade',0),2), 'Mrays/s', round(d['value']))"; }
+echo "== wide vs pair nodes"
+for cfg in "--config C3_suzanne" "--config C3_suzanne --spp 64" "--config C5_part2_all --spp 256" "--config C5_part2_all --spp 16" "--config C1_random_spheres" "--config teapot --spp 256"; do
+  for i in 1 2; do run "wide  $cfg" "$cfg" 3; FIREWORK_WIDE=0 run "pair  $cfg" "$cfg" 3; done
+done 2>&1 | tee $OUT/wide_ab.txt
+FIREWORK_WIDE=q8 run "q8    --config C3_suzanne" "--config C3_suzanne" 3 2>&1 | tee -a $OUT/wide_ab.txt
+FIREWORK_WIDE=q8 run "q8    --config C3_suzanne" "--config C3_suzanne" 3 2>&1 | tee -a $OUT/wide_ab.txt
+echo "== full-spp parity"
+timeout -k 10 500 python tools/full_parity.py --out $OUT/full_parity.jsonl C3_suzanne:512 teapot:64 C5_part2_all:256 2> $OUT/full_parity.err | cut -c1-330

@@ -1,11 +1,11 @@
 import os, sys, numpy as np
 sys.path.insert(0, os.getcwd())
-from firework_amd import scenes
+from firework_amd import _lib, scenes
 for name, spp in (("C5_part2_all", 8), ("C3_suzanne", 16), ("C1_random_spheres", 64)):
     s, r = scenes.config(name, None, None, spp)
-    os.environ.pop("FIREWORK_BVH", None)
+    _lib.set_option("BVH", None)
     a = r.render_full(s)
-    os.environ["FIREWORK_BVH"] = "median"
+    _lib.set_option("BVH", "median")
     b = r.render_full(s)
-    os.environ.pop("FIREWORK_BVH", None)
+    _lib.set_option("BVH", None)
     print(name, "rays", a.stats["rays"], b.stats["rays"], "identical image:", np.array_equal(a.linear, b.linear), "differing pixels:", int((a.linear != b.linear).any(axis=1).sum()))
