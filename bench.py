@@ -310,15 +310,26 @@ def one_shot_cold(args):
     fresh child process renders the frame once (code-object load, pool allocation, scene creation, render, D2H) and reports it."""
     code = ("import sys, time, json; sys.path.insert(0, %r)\n"
             "from firework_amd import scenes, _lib\n"
-            "s, r = scenes.config(%r, %r, %r, %r); sd = s.to_desc(); _lib.load()\n"
+            "s, r = scenes.config(%r, %r, %r, %r); sd = s.to_desc()\n"
+            "t0 = time.perf_counter(); _lib.load(); load_ms = (time.perf_counter() - t0) * 1e3\n"
             "t0 = time.perf_counter(); res = _lib.render_scene(sd, r); dt = (time.perf_counter() - t0) * 1e3\n"
             "st = res.stats\n"
-            "print(json.dumps(dict(ms_wall=dt, ms_library=st['ms_wall'], ms_scene=st['ms_scene'], ms_render=st['ms_render'], ms_d2h=st['ms_d2h'], mrays_per_s=st['rays'] / dt / 1e3)))\n"
-            % (ROOT, args.config, args.width, args.height, args.spp))
+            "out = dict(ms_wall=dt, ms_library=st['ms_wall'], ms_scene=st['ms_scene'], ms_render=st['ms_render'], ms_d2h=st['ms_d2h'], mrays_per_s=st['rays'] / dt / 1e3, ms_library_load=load_ms)\n"
+            "seq = []\n"
+            "for name in (%r):\n"
+            "    s2, r2 = scenes.config(name); sd2 = s2.to_desc(); w = []\n"
+            "    for rep in range(3):\n"
+            "        t0 = time.perf_counter(); _lib.render_scene(sd2, r2); w.append((time.perf_counter() - t0) * 1e3)\n"
+            "    seq.append(dict(config=name, first_ms=w[0], warm_ms=min(w[1:]), first_over_warm=w[0] / min(w[1:])))\n"
+            "out['then_first_calls_in_the_same_process'] = seq\n"
+            "print(json.dumps(out))\n"
+            % (ROOT, args.config, args.width, args.height, args.spp, ("C3_suzanne", "C4b_volume_test") if args.config == "C2_cornell_box" and not args.spp else ()))
     try:
         cp = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
         d = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
-        d["region"] = "first fw_render_scene call of a fresh process (library loaded, nothing else warm): wall = pools + code objects + scene + render + D2H"
+        d["region"] = ("first fw_render_scene call of a fresh process: wall = path arena + scene + render + D2H; the library's load (ms_library_load: HIP context, "
+                       "code objects, staging — its static initialiser) comes before it, like the loading of the reference's binary; then the first calls of two "
+                       "other configs in the same process (the arena may have to grow)")
         return d
     except Exception as e:
         return {"error": repr(e)}

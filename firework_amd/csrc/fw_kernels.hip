@@ -694,6 +694,13 @@ __device__ __forceinline__ bool hit_aabb(float4 lo, float4 hi, V3 o, V3 inv, flo
 // exit is within that of its entry.  Four such paths in part2's 1.8e9 at 256 spp, one in teapot's 2.7e8 (gpurun_out/r04a, r04b).
 constexpr float GATE_RELAX = 1.0f + 1.0f / 4096.0f;
 __device__ __forceinline__ V3 relaxed(V3 inv) { return mk(inv.x * GATE_RELAX, inv.y * GATE_RELAX, inv.z * GATE_RELAX); }
+// ... and the lower end of the interval the BOXES are clipped to (the item tests keep the caller's t_min).  A path that leaves a
+// surface starts ON a triangle's neighbour, whose plane it meets at t ~ 0; the computed t is that plus noise — (max|d| / |d_kz|)^2
+// ulps of the distance: 6e-5 at a shear of 32, 1.4e-3 at 150 — and the reference accepts it when the noise lifts it over
+// t_min = 0.001 (suzanne pixel 515109, sample 499: t = 0.00105 for a hit point 5e-6 from the origin).  The ray has left such a
+// triangle's own, thin box long before t_min, so a box test clipped at t_min never reaches it; the reference's does, through the
+// DoubleLeaf's union.  Boxes are therefore entered from 15/16 of t_min on, and from behind the origin for the SOFT class.
+__device__ __forceinline__ float box_tmin(float tmin, bool soft) { return tmin <= 0.f ? tmin : (soft ? -0.0625f : tmin * 0.9375f); }
 __device__ __forceinline__ bool hit_aabb_entry(float4 lo, float4 hi, V3 o, V3 inv, V3 inv_hi, float tmin, float tmax, float &entry) {
     const bool sx = inv.x < 0.f, sy = inv.y < 0.f, sz = inv.z < 0.f;
     tmin = fmaxf(tmin, ((sx ? hi.x : lo.x) - o.x) * inv.x); tmax = fminf(tmax, ((sx ? lo.x : hi.x) - o.x) * inv_hi.x);
@@ -702,26 +709,26 @@ __device__ __forceinline__ bool hit_aabb_entry(float4 lo, float4 hi, V3 o, V3 in
     entry = tmin;
     return tmax > tmin;
 }
-// mesh.rs:221-242: a triangle's own box (a flat axis padded by 0.001 on both sides), for tri_gate_ok
-__device__ __forceinline__ void triangle_box(V3 p0, V3 p1, V3 p2, float4 &lo, float4 &hi) {
-    lo = make_float4(fminf(fminf(p0.x, p1.x), p2.x), fminf(fminf(p0.y, p1.y), p2.y), fminf(fminf(p0.z, p1.z), p2.z), 0.f);
-    hi = make_float4(fmaxf(fmaxf(p0.x, p1.x), p2.x), fmaxf(fmaxf(p0.y, p1.y), p2.y), fmaxf(fmaxf(p0.z, p1.z), p2.z), 0.f);
-    if (fabsf(hi.x - lo.x) < 0.001f) { lo.x -= 0.001f; hi.x += 0.001f; }
-    if (fabsf(hi.y - lo.y) < 0.001f) { lo.y -= 0.001f; hi.y += 0.001f; }
-    if (fabsf(hi.z - lo.z) < 0.001f) { lo.z -= 0.001f; hi.z += 0.001f; }
-}
 // The reference's gating rule, exact (round 4).  bvh.rs:115-151 tests an item iff the ray passes the box of every node down to the
 // item's LEAF NODE — i.e. iff it passes that node's box (a DoubleLeaf's is the union of its two items'; the ancestors' are supersets
 // and the slab arithmetic is monotone).  The walked trees hold the items' own boxes, relaxed (hit_aabb_entry), so a hit that is about
 // to become its ray's best is put to the rule itself, with the reference's own test (hit_aabb, the caller's [tmin, tmax]):
-//   triangle: its own box (recomputed from the vertices: no fetch) is inside its leaf node's, so passing it suffices; otherwise the
-//             leaf node's box decides (tri_gate, 32 B from HBM: one hit in ~1e7);
+//   triangle: the box of its three vertices is inside its leaf node's, so passing it suffices (no fetch); otherwise the leaf node's
+//             box decides (tri_gate, 32 B from HBM: flat axis-aligned triangles, and one other hit in ~1e7);
 //   object:   its reference leaf-node box (obj_gate), fetched with the object record.
 __device__ __forceinline__ bool tri_gate_ok(const DScene &sc, size_t tri, V3 p0, V3 p1, V3 p2, V3 o, V3 inv, float tmin, float tmax) {
-    float4 lo, hi;
-    triangle_box(p0, p1, p2, lo, hi);
-    if (hit_aabb(lo, hi, o, inv, tmin, tmax)) return true;
-    return hit_aabb(sc.tri_gate[2 * tri], sc.tri_gate[2 * tri + 1], o, inv, tmin, tmax);
+    // Sufficient, and all that nearly every hit needs: the box of the three vertices WITHOUT mesh.rs:230-241's padding of flat axes,
+    // entry = the smaller and exit = the larger of an axis' two plane distances.  With lo <= hi the smaller IS the plane the
+    // reference picks by the sign of 1/d (the slab arithmetic is monotone; a NaN distance — the origin in a plane it runs along —
+    // makes this form fail where the reference ignores it, which only sends the hit to the exact test below); the padded box and the
+    // leaf node's contain this one.  ~30 instructions, nothing fetched.
+    const float lx = fminf(fminf(p0.x, p1.x), p2.x), ly = fminf(fminf(p0.y, p1.y), p2.y), lz = fminf(fminf(p0.z, p1.z), p2.z);
+    const float hx = fmaxf(fmaxf(p0.x, p1.x), p2.x), hy = fmaxf(fmaxf(p0.y, p1.y), p2.y), hz = fmaxf(fmaxf(p0.z, p1.z), p2.z);
+    const float ax = (lx - o.x) * inv.x, bx = (hx - o.x) * inv.x, ay = (ly - o.y) * inv.y, by = (hy - o.y) * inv.y, az = (lz - o.z) * inv.z, bz = (hz - o.z) * inv.z;
+    const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), tmin);
+    const float tf = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), tmax);
+    if (tf > tn) return true;
+    return hit_aabb(sc.tri_gate[2 * tri], sc.tri_gate[2 * tri + 1], o, inv, tmin, tmax);     // the rule itself: the reference leaf node's box, aabb.rs:30-50
 }
 __device__ __forceinline__ bool obj_gate_ok(const DScene &sc, uint32_t k, V3 o, V3 inv) {
     return hit_aabb(sc.obj_gate[2 * (size_t)k], sc.obj_gate[2 * (size_t)k + 1], o, inv, 0.001f, 2e9f);      // render.rs:19: the walk's [t_min, t_max]
@@ -811,7 +818,7 @@ __device__ __forceinline__ bool hit_mesh(const DScene &sc, uint32_t root, uint32
         while (!(cur & REF_LEAF)) {
             TS_TICK(4);
             // cull_t: a t the caller already holds from another object (hits beyond it cannot win; equal t still can)
-            cur = pair_step(sc.blas, cur, r.o, inv, relaxed(inv), tmin, tmax, soft ? NO_CULL : cull_bound(have ? fminf(best, cull_t) : cull_t), st);
+            cur = pair_step(sc.blas, cur, r.o, inv, relaxed(inv), box_tmin(tmin, soft), tmax, soft ? NO_CULL : cull_bound(have ? fminf(best, cull_t) : cull_t), st);
         }
         if (cur == REF_DONE) break;
         const uint32_t item = cur & NODE_MASK;
@@ -1062,6 +1069,15 @@ constexpr uint32_t WALK_NUM = FW_WALK_NUM, WALK_DEN = FW_WALK_DEN;   // same rul
 static_assert(FW_BLAS_WALK_NUM > FW_BLAS_WALK_DEN, "the walk must continue while every busy lane walks");
 constexpr uint32_t BLAS_WALK_NUM = FW_BLAS_WALK_NUM, BLAS_WALK_DEN = FW_BLAS_WALK_DEN;   // node walking stops when walkers * NUM <= busy lanes * DEN
 static_assert(FW_WB == 64, "the parked-ray list and the wave-private queues assume single-wave workgroups");
+static_assert(FW_TLAS_SCAN_MAX <= 24, "k_extend_scan parks a ray with a bit mask of its meshes");
+// a parked entry's second word: the mesh object to walk, or PARK_MASK | a bit per mesh object (k_extend_scan: all the meshes the ray reaches)
+constexpr uint32_t PARK_MASK = 0x80000000u;
+__device__ __forceinline__ uint32_t park_next_mesh(uint32_t &word) {       // -> the next object to walk; word = what is left (0: nothing)
+    if (!(word & PARK_MASK)) { const uint32_t obj = word; word = 0u; return obj; }
+    const uint32_t m = word & ~PARK_MASK, obj = (uint32_t)__ffs((int)m) - 1u, rest = m & (m - 1u);
+    word = rest ? (PARK_MASK | rest) : 0u;
+    return obj;
+}
 
 // The LDS-resident walks (k_blas_lds, k_extend_tlas_lds) read the entries of SEVERAL wave queues as one stream of blocks of
 // <= 64 (one register read-ahead buffer each): a wave that has handed out its queue takes the next one of its workgroup, so
@@ -1142,7 +1158,7 @@ __device__ __forceinline__ void hoisted_hits(const DScene &sc, const Ray &r, V3 
     for (uint32_t h = 0; h < sc.n_hoisted; h++) {
         const uint32_t k = sc.hoisted[h];
         float entry;
-        if (!hit_aabb_entry(sc.obj_leaf[2 * (size_t)k], sc.obj_leaf[2 * (size_t)k + 1], r.o, inv, relaxed(inv), TMIN, TMAX, entry)) continue;
+        if (!hit_aabb_entry(sc.obj_leaf[2 * (size_t)k], sc.obj_leaf[2 * (size_t)k + 1], r.o, inv, relaxed(inv), box_tmin(TMIN, false), TMAX, entry)) continue;
         Obj o = load_obj(sc.obj, k);
         float t; uint32_t prim;
         if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
@@ -1221,7 +1237,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
                 if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;   // n_walk < n_busy: somebody holds a leaf or has finished
                 if (walking) {
                     TS_TICK(0);
-                    cur = pair_step(sc.tlas, cur, r.o, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? best_t : TMAX), st);
+                    cur = pair_step(sc.tlas, cur, r.o, inv, relaxed(inv), box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? best_t : TMAX), st);
                 }
             }
             if (!busy || !(cur & REF_LEAF) || cur == REF_DONE) continue;
@@ -1303,7 +1319,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                 if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;   // n_walk < n_act: somebody holds a leaf, the round makes progress
                 if (walking) {
                     TS_TICK(4);
-                    cur = pair_step(sc.blas, cur, ro, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+                    cur = pair_step(sc.blas, cur, ro, inv, relaxed(inv), box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
                 }
             }
             if (act && (cur & REF_LEAF)) {
@@ -1399,7 +1415,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
                 if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
                 if (walking) {
                     TS_TICK(0);
-                    cur = pair_step(sc.tlas, cur, wo, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? best_t : TMAX), st);
+                    cur = pair_step(sc.tlas, cur, wo, inv, relaxed(inv), box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? best_t : TMAX), st);
                 }
             }
             if (busy && (cur & REF_LEAF) && cur != REF_DONE) {
@@ -1528,11 +1544,11 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVE
             for (uint32_t k = 0; k < n_obj; k++) {
                 const float4 lo = sc.obj_leaf[2 * (size_t)k], hi = sc.obj_leaf[2 * (size_t)k + 1];   // the leaf's box in the walked tree
                 float entry;
-                if (!hit_aabb_entry(lo, hi, r.o, inv, relaxed(inv), TMIN, TMAX, entry) || entry > (soft ? NO_CULL : cull_bound(have ? best_t : TMAX))) continue;
+                if (!hit_aabb_entry(lo, hi, r.o, inv, relaxed(inv), box_tmin(TMIN, soft), TMAX, entry) || entry > (soft ? NO_CULL : cull_bound(have ? best_t : TMAX))) continue;
                 Obj o = load_obj(sc.obj, k);
-                if (PARK && obj_kind(o) == 5u && !deferred) {                // the first mesh is parked — if the reference's walk reaches it (obj_gate_ok)
-                    if (obj_gate_ok(sc, k, r.o, inv)) { deferred = true; deferred_obj = k; }
-                    continue;
+                if (PARK && obj_kind(o) == 5u) {                // EVERY mesh the reference's walk reaches (obj_gate_ok) goes on the ray's list: k_blas* walks them one
+                    if (obj_gate_ok(sc, k, r.o, inv)) { deferred = true; deferred_obj |= 1u << k; }      // after the other (round 4: until then only the first was
+                    continue;                                                                            // parked, the others were walked here, in place, from L2)
                 }
                 float t; uint32_t prim;
                 if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
@@ -1549,7 +1565,7 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVE
                     const uint32_t e = w * park_stride + park_n + prank;
                     qst(&park_a[e], make_float4(r.o.x, r.o.y, r.o.z, r.d.x));
                     qst(&park_b[e], make_float2(r.d.y, r.d.z));
-                    qst(&park_m[e], make_float4(__uint_as_float(i), __uint_as_float(deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
+                    qst(&park_m[e], make_float4(__uint_as_float(i), __uint_as_float(PARK_MASK | deferred_obj), best_t, pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y));
                 }
                 park_n += (uint32_t)__popcll(pmask);
             }
@@ -1730,6 +1746,17 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
     bool soft = false;
     TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
     LdsStack st{lds_stack + threadIdx.x, 0};
+    uint32_t more = 0, pidx = 0;            // the meshes this ray still has to walk after the current one (park_next_mesh), and where its parked entry lies
+    auto start_walk = [&](uint32_t mesh_obj, float4 ra, float2 rb) {
+        obj = mesh_obj;
+        Obj o = load_obj(sc.obj, obj);
+        Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
+        ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+        soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
+        tr = make_triray(r);
+        tri_base = o.aux1; cur = o.aux0; st.sp = 0;
+        have = false; mbest = TMAX; mtri = 0; act = true;
+    };
     for (;;) {
         const unsigned long long idle_mask = __ballot(!act);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
@@ -1743,14 +1770,9 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
                 const float2 rb = make_float2(bp(cb.x), bp(cb.y));
                 const float4 me = make_float4(bp(cm.x), bp(cm.y), bp(cm.z), bp(cm.w));
                 if (!act && rank < take) {
-                    slot = __float_as_uint(me.x); obj = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
-                    Obj o = load_obj(sc.obj, obj);
-                    Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
-                    ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
-                    soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
-                    tr = make_triray(r);
-                    tri_base = o.aux1; cur = o.aux0; st.sp = 0;
-                    have = false; mbest = TMAX; mtri = 0; act = true;
+                    slot = __float_as_uint(me.x); more = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
+                    pidx = base + q_next + rank;
+                    start_walk(park_next_mesh(more), ra, rb);
                 }
                 q_next += take;
                 if (q_next == cur_base + 64u && q_next < n) { ca = na; cb = nb; cm = nm; cur_base += 64u; fetch(cur_base + 64u + lane, na, nb, nm); }
@@ -1766,7 +1788,7 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
             if (walking) {
                 TS_TICK(4);
-                cur = pair_step(sc.blas, cur, ro, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+                cur = pair_step(sc.blas, cur, ro, inv, relaxed(inv), box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
             }
         }
         if (act && (cur & REF_LEAF)) {
@@ -1785,8 +1807,8 @@ void k_blas(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q) {
             if (cur == REF_DONE) {                                      // finished: merge with what the TLAS walk held
                 const uint32_t bobj = bcode == MISS ? MISS : (bcode >> sc.prim_bits);
                 if (have && (bobj == MISS || mbest < bt || (mbest == bt && sc.obj_rank[obj] > sc.obj_rank[bobj]))) { bt = mbest; bcode = (obj << sc.prim_bits) | mtri; }
-                qst(&hits[slot], make_float2(bt, __uint_as_float(bcode)));
-                act = false;
+                if (more) start_walk(park_next_mesh(more), qld(&park.ray_a[pidx]), qld(&park.ray_b[pidx]));      // the ray's next mesh (k_extend_scan's mask)
+                else { qst(&hits[slot], make_float2(bt, __uint_as_float(bcode))); act = false; }
             }
         }
     }
@@ -1849,9 +1871,9 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
     auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float4 &m) {
         if (lane < b_n) { a = qld(&park.ray_a[b_base + lane]); b = qld(&park.ray_b[b_base + lane]); m = qld(&park.meta[b_base + lane]); }
     };
-    uint32_t c_n = 0, c_pos = 0, n_n = 0, bb = 0;
-    if (bs.next(bb, c_n)) fetch(bb, c_n, ca, cb, cm); else c_n = 0;
-    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+    uint32_t c_n = 0, c_pos = 0, n_n = 0, bb = 0, c_bb = 0, n_bb = 0;         // c_bb / n_bb: first parked entry of the current / next block
+    if (bs.next(bb, c_n)) { fetch(bb, c_n, ca, cb, cm); c_bb = bb; } else c_n = 0;
+    if (c_n && bs.next(bb, n_n)) { fetch(bb, n_n, na, nb, nm); n_bb = bb; } else n_n = 0;
     bool act = false, have = false;
     uint32_t slot = 0, obj = 0, tri_base = 0, bcode = MISS, mtri = 0, cur = REF_DONE;
     float bt = TMAX, mbest = TMAX;
@@ -1860,6 +1882,17 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
     bool soft = false;
     TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
     LdsStack16 st{stacks + (size_t)wib * levels * 64u + lane, 0};
+    uint32_t more = 0, pidx = 0;            // the meshes this ray still has to walk after the current one (park_next_mesh), and where its parked entry lies
+    auto start_walk = [&](uint32_t mesh_obj, float4 ra, float2 rb) {
+        obj = mesh_obj;
+        Obj o = load_obj(sc.obj, obj);
+        Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
+        ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+        soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
+        tr = make_triray(r);
+        tri_base = o.aux1; cur = o.aux0; st.sp = 0;
+        have = false; mbest = TMAX; mtri = 0; act = true;
+    };
     for (;;) {
         const unsigned long long idle_mask = __ballot(!act);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
@@ -1873,19 +1906,14 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
                 const float2 rb = make_float2(bp(cb.x), bp(cb.y));
                 const float4 me = make_float4(bp(cm.x), bp(cm.y), bp(cm.z), bp(cm.w));
                 if (!act && rank < take) {
-                    slot = __float_as_uint(me.x); obj = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
-                    Obj o = load_obj(sc.obj, obj);
-                    Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
-                    ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
-                    soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
-                    tr = make_triray(r);
-                    tri_base = o.aux1; cur = o.aux0; st.sp = 0;
-                    have = false; mbest = TMAX; mtri = 0; act = true;
+                    slot = __float_as_uint(me.x); more = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
+                    pidx = c_bb + c_pos + rank;
+                    start_walk(park_next_mesh(more), ra, rb);
                 }
                 c_pos += take;
                 if (c_pos == c_n) {
-                    ca = na; cb = nb; cm = nm; c_n = n_n; c_pos = 0;
-                    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+                    ca = na; cb = nb; cm = nm; c_n = n_n; c_pos = 0; c_bb = n_bb;
+                    if (c_n && bs.next(bb, n_n)) { fetch(bb, n_n, na, nb, nm); n_bb = bb; } else n_n = 0;
                 }
             }
         } else if (n_idle == 64u) break;
@@ -1900,10 +1928,10 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
             const bool walking = act && !(cur & REF_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
-            if (walking) cur = pair_step(lds_nodes, cur, ro, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+            if (walking) cur = pair_step(lds_nodes, cur, ro, inv, relaxed(inv), box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
             // two steps per exit check: the ballot, the count and the exit rule cost a third of a step's issue time
             // (suzanne @64 10.1 -> 9.9 ms; the TLAS walk of part2 gains nothing from the same and keeps one)
-            if (act && !(cur & REF_LEAF)) cur = pair_step(lds_nodes, cur, ro, inv, relaxed(inv), TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+            if (act && !(cur & REF_LEAF)) cur = pair_step(lds_nodes, cur, ro, inv, relaxed(inv), box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
         }
         for (int pass = 0; pass < 2; pass++) {                         // the triangles put aside, then the ones held
             uint32_t item = REF_DONE;
@@ -1924,8 +1952,8 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_blas_lds(DScene sc, DPark pa
             if (cur == REF_DONE) {
                 const uint32_t bobj = bcode == MISS ? MISS : (bcode >> sc.prim_bits);
                 if (have && (bobj == MISS || mbest < bt || (mbest == bt && sc.obj_rank[obj] > sc.obj_rank[bobj]))) { bt = mbest; bcode = (obj << sc.prim_bits) | mtri; }
-                qst(&hits[slot], make_float2(bt, __uint_as_float(bcode)));
-                act = false;
+                if (more) start_walk(park_next_mesh(more), qld(&park.ray_a[pidx]), qld(&park.ray_b[pidx]));      // the ray's next mesh (k_extend_scan's mask)
+                else { qst(&hits[slot], make_float2(bt, __uint_as_float(bcode))); act = false; }
             }
         }
     }
@@ -2026,7 +2054,7 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
             const bool walking = busy && !(cur & REF_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
-            if (walking) cur = pair_step(lds_nodes, cur, wo, inv, relaxed(inv), TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
+            if (walking) cur = pair_step(lds_nodes, cur, wo, inv, relaxed(inv), box_tmin(TMIN, false), TMAX, cull_bound(have ? best_t : TMAX), st);
         }
         if (busy && (cur & REF_LEAF) && cur != REF_DONE) {
             const uint32_t item = cur & NODE_MASK;
@@ -2065,13 +2093,13 @@ struct LdsStackW {   // 16-bit references, [level][lane] over the 64 lanes of on
     __device__ __forceinline__ void push(uint32_t v) { s[sp * 64] = (uint16_t)v; sp++; }
     __device__ __forceinline__ uint32_t pop() { sp--; return s[sp * 64]; }
 };
-// per ray: WIDE_F32 byte offsets (inside a node) of the near planes of x, y, z and of the far planes; WIDE_Q8: q[0..2] = inv < 0
-struct WideSel { uint32_t q[6]; };
+// per ray: WIDE_F32 byte offsets (inside a node) of the near planes of x, y, z (the far planes lie at 48 - q[0], 80 - q[1], 112 - q[2]); WIDE_Q8: q[0..2] = inv < 0
+struct WideSel { uint32_t q[3]; };
 template <int FMT> __device__ __forceinline__ WideSel wide_sel(V3 inv) {
     WideSel s;
     const bool nx = inv.x < 0.f, ny = inv.y < 0.f, nz = inv.z < 0.f;       // the selection of aabb.rs:36-38 (`if inv_d < 0 { swap }`)
-    if (FMT == WIDE_F32) { s.q[0] = nx ? 48u : 0u; s.q[1] = ny ? 64u : 16u; s.q[2] = nz ? 80u : 32u; s.q[3] = nx ? 0u : 48u; s.q[4] = ny ? 16u : 64u; s.q[5] = nz ? 32u : 80u; }
-    else { s.q[0] = nx ? 1u : 0u; s.q[1] = ny ? 1u : 0u; s.q[2] = nz ? 1u : 0u; s.q[3] = s.q[4] = s.q[5] = 0u; }
+    if (FMT == WIDE_F32) { s.q[0] = nx ? 48u : 0u; s.q[1] = ny ? 64u : 16u; s.q[2] = nz ? 80u : 32u; }
+    else { s.q[0] = nx ? 1u : 0u; s.q[1] = ny ? 1u : 0u; s.q[2] = nz ? 1u : 0u; }
     return s;
 }
 template <int FMT>
@@ -2081,7 +2109,7 @@ __device__ __forceinline__ uint32_t wide_step(const uint32_t *__restrict__ nodes
     if (FMT == WIDE_F32) {
         const char *nd = reinterpret_cast<const char *>(nodes) + __umul24(node, WIDE_F32_DW * 4u);     // node < 2^15: the 24-bit multiply is full rate
         NX = *reinterpret_cast<const float4 *>(nd + sel.q[0]); NY = *reinterpret_cast<const float4 *>(nd + sel.q[1]); NZ = *reinterpret_cast<const float4 *>(nd + sel.q[2]);
-        FX = *reinterpret_cast<const float4 *>(nd + sel.q[3]); FY = *reinterpret_cast<const float4 *>(nd + sel.q[4]); FZ = *reinterpret_cast<const float4 *>(nd + sel.q[5]);
+        FX = *reinterpret_cast<const float4 *>(nd + (48u - sel.q[0])); FY = *reinterpret_cast<const float4 *>(nd + (80u - sel.q[1])); FZ = *reinterpret_cast<const float4 *>(nd + (112u - sel.q[2]));
         const uint2 rr = *reinterpret_cast<const uint2 *>(nd + 96);
         r01 = rr.x; r23 = rr.y;
     } else {
@@ -2123,9 +2151,12 @@ __device__ __forceinline__ void stage_lds(uint32_t *__restrict__ dst, const uint
     for (uint32_t k = threadIdx.x; k < dwords / 4u; k += blockDim.x) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
 }
 constexpr int WIDE_MAX_WAVES = 16;
+#ifndef FW_WIDE_WAVES
+#define FW_WIDE_WAVES 4     // register budget of k_blas_wide (waves per SIMD it must leave room for): its own 16 waves per CU are 4 per SIMD; what is
+#endif                      // left of the register file is where the other batch's kernels run
 // Dynamic LDS: [wide nodes][triangles (LDS_TRIS)][stacks: waves x levels x 64 u16][counter, 4 dwords][this workgroup's queue counts]
 template <int FMT, bool LDS_TRIS>
-__global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_blas_wide(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q,
+__global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_per_eu(FW_WIDE_WAVES, 8))) void k_blas_wide(DScene sc, DPark park, float2 *__restrict__ hits, DQueue q,
                                                                    uint32_t n_nodes, uint32_t n_tris, uint32_t levels) {
     extern __shared__ uint32_t lds_w[];
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6, n_waves_wg = blockDim.x >> 6;
@@ -2149,9 +2180,9 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_blas_wide(DScene sc, DP
     auto fetch = [&](uint32_t b_base, uint32_t b_n, float4 &a, float2 &b, float4 &m) {
         if (lane < b_n) { a = qld(&park.ray_a[b_base + lane]); b = qld(&park.ray_b[b_base + lane]); m = qld(&park.meta[b_base + lane]); }
     };
-    uint32_t c_n = 0, c_pos = 0, n_n = 0, bb = 0;
-    if (bs.next(bb, c_n)) fetch(bb, c_n, ca, cb, cm); else c_n = 0;
-    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+    uint32_t c_n = 0, c_pos = 0, n_n = 0, bb = 0, c_bb = 0, n_bb = 0;         // c_bb / n_bb: first parked entry of the current / next block
+    if (bs.next(bb, c_n)) { fetch(bb, c_n, ca, cb, cm); c_bb = bb; } else c_n = 0;
+    if (c_n && bs.next(bb, n_n)) { fetch(bb, n_n, na, nb, nm); n_bb = bb; } else n_n = 0;
     bool act = false, have = false;
     uint32_t slot = 0, obj = 0, tri_base = 0, bcode = MISS, mtri = 0, cur = W_DONE, pend = W_DONE;
     float bt = TMAX, mbest = TMAX;
@@ -2160,6 +2191,18 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_blas_wide(DScene sc, DP
     WideSel sel = wide_sel<FMT>(inv);
     TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
     LdsStackW st{stacks + (size_t)wib * levels * 64u + lane, 0};
+    uint32_t more = 0, pidx = 0;            // the meshes this ray still has to walk after the current one (park_next_mesh), and where its parked entry lies
+    auto start_walk = [&](uint32_t mesh_obj, float4 ra, float2 rb) {
+        obj = mesh_obj;
+        Obj o = load_obj(sc.obj, obj);
+        Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
+        ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
+        sel = wide_sel<FMT>(inv);
+        soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
+        tr = make_triray(r);
+        tri_base = o.aux1; cur = sc.obj_wroot[obj]; st.sp = 0;
+        have = false; mbest = TMAX; mtri = 0; act = true;
+    };
     for (;;) {
         const unsigned long long idle_mask = __ballot(!act);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
@@ -2173,20 +2216,14 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_blas_wide(DScene sc, DP
                 const float2 rb = make_float2(bp(cb.x), bp(cb.y));
                 const float4 me = make_float4(bp(cm.x), bp(cm.y), bp(cm.z), bp(cm.w));
                 if (!act && rank < take) {
-                    slot = __float_as_uint(me.x); obj = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
-                    Obj o = load_obj(sc.obj, obj);
-                    Ray r = to_object_space(o, Ray{mk(ra.x, ra.y, ra.z), mk(ra.w, rb.x, rb.y)});
-                    ro = r.o; inv = mk(fdiv(1.f, r.d.x), fdiv(1.f, r.d.y), fdiv(1.f, r.d.z));
-                    sel = wide_sel<FMT>(inv);
-                    soft = soft_direction(r.d.x, r.d.y, r.d.z, sc.soft_shear);
-                    tr = make_triray(r);
-                    tri_base = o.aux1; cur = sc.obj_wroot[obj]; st.sp = 0;
-                    have = false; mbest = TMAX; mtri = 0; act = true;
+                    slot = __float_as_uint(me.x); more = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
+                    pidx = c_bb + c_pos + rank;
+                    start_walk(park_next_mesh(more), ra, rb);
                 }
                 c_pos += take;
                 if (c_pos == c_n) {
-                    ca = na; cb = nb; cm = nm; c_n = n_n; c_pos = 0;
-                    if (c_n && bs.next(bb, n_n)) fetch(bb, n_n, na, nb, nm); else n_n = 0;
+                    ca = na; cb = nb; cm = nm; c_n = n_n; c_pos = 0; c_bb = n_bb;
+                    if (c_n && bs.next(bb, n_n)) { fetch(bb, n_n, na, nb, nm); n_bb = bb; } else n_n = 0;
                 }
             }
         } else if (n_idle == 64u) break;
@@ -2198,9 +2235,13 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_blas_wide(DScene sc, DP
             const bool walking = act && !(cur & W_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
-            if (walking) cur = wide_step<FMT>(lds_w, cur, ro, inv, relaxed(inv), sel, TMIN, TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+            if (walking) cur = wide_step<FMT>(lds_w, cur, ro, inv, relaxed(inv), sel, box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
         }
-        for (int pass = 0; pass < 2; pass++) {                         // the triangles put aside, then the ones held
+        // The round's triangle tests: the one put aside, then the one held.  A hit that would become the ray's best is a CANDIDATE; the
+        // reference's gating rule (tri_gate_ok) is applied once per round, to the nearer of the two, and to the other only if that one
+        // fails it (it costs as much as a third of a triangle test, and inside the loop it ran twice per round for the few lanes with a hit).
+        float ct0 = 0.f, ct1 = 0.f; uint32_t ci0 = W_DONE, ci1 = W_DONE;
+        for (int pass = 0; pass < 2; pass++) {
             uint32_t item = W_DONE;
             if (pass == 0) { if (act && pend != W_DONE) { item = pend & 0x7fffu; pend = W_DONE; } }
             else if (act && (cur & W_LEAF) && cur != W_DONE) { item = cur & 0x7fffu; cur = st.sp ? st.pop() : W_DONE; }
@@ -2210,16 +2251,30 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_blas_wide(DScene sc, DP
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, b0, b1, b2;
                 if (hit_triangle(mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), tr, TMIN, TMAX, t, b0, b1, b2)) {
-                    if ((!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) &&
-                        tri_gate_ok(sc, tri_base + item, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, inv, TMIN, TMAX)) { have = true; mbest = t; mtri = item; }
+                    if (!have || t < mbest || (t == mbest && sc.tri_rank[tri_base + item] > sc.tri_rank[tri_base + mtri])) {
+                        if (pass == 0) { ct0 = t; ci0 = item; } else { ct1 = t; ci1 = item; }
+                    }
                 }
+            }
+        }
+        if (ci1 != W_DONE && (ci0 == W_DONE || ct1 < ct0 || (ct1 == ct0 && sc.tri_rank[tri_base + ci1] > sc.tri_rank[tri_base + ci0]))) {
+            const float tt = ct0; ct0 = ct1; ct1 = tt; const uint32_t ti = ci0; ci0 = ci1; ci1 = ti;      // the nearer (on a tie: the later in the reference's order) first
+        }
+        for (int k = 0; k < 2; k++) {
+            const uint32_t ci = k ? ci1 : ci0; const float ct = k ? ct1 : ct0;
+            const bool want = ci != W_DONE && (!have || ct < mbest || (ct == mbest && sc.tri_rank[tri_base + ci] > sc.tri_rank[tri_base + mtri]));
+            if (__ballot(want) == 0ull) continue;
+            if (want) {
+                const float4 *tp = (LDS_TRIS ? lds_tris : sc.tri) + 3 * (size_t)(tri_base + ci);
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                if (tri_gate_ok(sc, tri_base + ci, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, inv, TMIN, TMAX)) { have = true; mbest = ct; mtri = ci; }
             }
         }
         if (act && cur == W_DONE) {
             const uint32_t bobj = bcode == MISS ? MISS : (bcode >> sc.prim_bits);
             if (have && (bobj == MISS || mbest < bt || (mbest == bt && sc.obj_rank[obj] > sc.obj_rank[bobj]))) { bt = mbest; bcode = (obj << sc.prim_bits) | mtri; }
-            qst(&hits[slot], make_float2(bt, __uint_as_float(bcode)));
-            act = false;
+            if (more) start_walk(park_next_mesh(more), qld(&park.ray_a[pidx]), qld(&park.ray_b[pidx]));      // the ray's next mesh (k_extend_scan's mask)
+            else { qst(&hits[slot], make_float2(bt, __uint_as_float(bcode))); act = false; }
         }
     }
 }
@@ -2311,7 +2366,7 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene
             const bool walking = busy && !(cur & W_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
-            if (walking) cur = wide_step<WIDE_F32>(lds_w, cur, wo, inv, relaxed(inv), sel, TMIN, TMAX, cull_bound(have ? best_t : TMAX), st);
+            if (walking) cur = wide_step<WIDE_F32>(lds_w, cur, wo, inv, relaxed(inv), sel, box_tmin(TMIN, false), TMAX, cull_bound(have ? best_t : TMAX), st);
         }
         if (busy && (cur & W_LEAF) && cur != W_DONE) {
             const uint32_t item = cur & 0x7fffu;

@@ -75,6 +75,9 @@ def main():
     assert im.shape == (800, 600, 3)
     lat["part2_turbulence_window"] = np.ascontiguousarray(im[325:515, 180:370])
     lat["part2_turbulence_window_meta"] = np.array([600, 800, 180, 325, 370, 515], np.int32)     # width, height, x0, y0, x1, y1
+    # ... and the 200x200 window around the MetalMat sphere (albedo .8 .8 .9, roughness 10) at (0, 1.5, 1.45): nothing random on it either
+    lat["part2_metal_window"] = np.ascontiguousarray(im[496:696, 248:448])
+    lat["part2_metal_window_meta"] = np.array([600, 800, 248, 496, 448, 696], np.int32)
     np.savez_compressed(f"{ROOT}/tests/golden/reference_png_lattice.npz", **lat)
     shutil.copyfile(f"{REF}/uvmap.png", f"{ROOT}/scenes/uvmap.png")
 

@@ -19,8 +19,8 @@ Each image is compared at gamma 2.2 (render.rs:214, today's default) AND at gamm
   volume.png       volume_test.rs 960x540 @2048     2.2      ConstantMedium (log10 free path), IsotropicMat, DielectricMat — with the
                                                              example's radii at 1.5 / 1.51 (the PNG predates today's 1.0 / 1.01)
 
-  part2_final.png  part2_all.rs 600x800 @10000 BVH  2.2      the TurbulenceTexture sphere's pattern only (Perlin noise, turbulence): box
-                                                             heights and the small spheres come from tiny_rng, the example is API-stale
+  part2_final.png  part2_all.rs 600x800 @10000 BVH  2.2      the TurbulenceTexture sphere's pattern (Perlin noise, turbulence) and the MetalMat sphere's
+                                                             luminance profile (round 4): box heights and the small spheres come from tiny_rng, the example is API-stale
 
 Not usable: random_spheres.png (its camera is not the example's: the horizon sits on row 169 instead of 182, the metal sphere
 has radius 119 px instead of 106 and its centre is 19 px further right — not a pure zoom — and the checker squares are larger;
@@ -168,3 +168,41 @@ def test_part2_final_png_pins_the_turbulence_pattern(oracle):
     corr = float(np.corrcoef(win.mean(2)[inside], img.mean(2)[inside])[0, 1])
     print(f"\npart2_final.png turbulence sphere: black-map agreement {agree:.3f} (shifted by 6 px: {shifted:.3f}), luminance correlation {corr:.3f}")
     assert agree > 0.85 and shifted < 0.68 and corr > 0.85
+
+
+def test_part2_final_png_pins_the_metal_sphere(oracle):
+    """examples/part2_all.rs:39-40 — `MetalMat::new(Vec3::new(0.8, 0.8, 0.9), 10.)` on the sphere of radius 0.5 at (0, 1.5, 1.45): the
+    only reference output MetalMat has.  Nothing on that sphere is random (the box heights that light its underside are, mildly).
+    material.rs:90-107 reflects the UNNORMALISED ray direction (length ~10 for a camera ray) and adds roughness x a point of the unit
+    ball, so at roughness 10 the lobe is a Lambertian-like one about the MIRROR direction, absorbed below the surface: a bright cap,
+    a dark band where the mirror direction points at the dark far wall, a green-lit underside — part2_final.png shows exactly that.
+    Compared: the luminance profile of the sphere's disc in fourteen horizontal strips, oracle (128 spp, every 2nd pixel) against the
+    PNG (10 000 spp).  As written: correlation 0.999, strips 9 grey levels apart (the underside's boxes differ).  With a
+    LambertianMat of the same colour in its place the correlation is 0.24, with roughness 0 or 1 0.41 / 0.55: the profile pins the
+    reflection about the normal, the unnormalised direction against the roughness, and the absorption rule."""
+    from firework_amd.api import LambertianMat
+    win = LATTICE["part2_metal_window"].astype(np.float64)
+    width, height, x0, y0, x1, y1 = (int(v) for v in LATTICE["part2_metal_window_meta"])
+    ys, xs = np.meshgrid(np.arange(y0, y1, 2), np.arange(x0, x1, 2), indexing="ij")
+    ref = win[::2, ::2].mean(2)
+    inside = np.hypot(xs - 348.4, ys - 596.3) < 58                # the sphere's disc (camera.rs projection of its centre; radius 65 px)
+
+    def profile(lum):
+        return np.array([lum[inside & (ys >= r0) & (ys < r0 + 8)].mean() for r0 in range(540, 652, 8)])
+
+    def render(as_written):
+        scene, renderer = scenes.part2_all()
+        assert type(scene.materials[4]).__name__ == "MetalMat"
+        if not as_written:
+            scene.materials[4] = LambertianMat.with_color((0.8, 0.8, 0.9))
+        renderer.width(width).height(height).samples(128)
+        res = oracle.render(scene, renderer, pixel_ids=(ys * width + xs).reshape(-1).astype(np.uint32))
+        lin = np.clip(np.nan_to_num(res.linear.astype(np.float64)), 0.0, None)
+        return np.floor(np.clip(lin ** (1.0 / 2.2), 0.0, 1.0) * 255.99).reshape(ys.shape + (3,)).mean(2)
+
+    p_ref, p_metal, p_lambert = profile(ref), profile(render(True)), profile(render(False))
+    c_metal, c_lambert = float(np.corrcoef(p_ref, p_metal)[0, 1]), float(np.corrcoef(p_ref, p_lambert)[0, 1])
+    d_metal = float(np.abs(p_ref - p_metal).mean())
+    print(f"\npart2_final.png metal sphere: strip profile correlation {c_metal:.3f} (a Lambertian in its place: {c_lambert:.3f}), mean strip difference {d_metal:.1f} grey levels")
+    assert c_metal > 0.99 and d_metal < 14.0
+    assert c_lambert < 0.6

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 4: suite + full-spp parity of the tree configs + wide / pair / wide at 96 registers
+set -o pipefail
+OUT=$PWD/gpurun_out/$1; mkdir -p $OUT
+R=$PWD
+timeout -k 10 600 python -m pytest tests -m gpu -q 2>&1 | tee $OUT/pytest.log | tail -12; echo "pytest rc=$?"
+echo "== full-spp parity"
+timeout -k 10 600 python tools/full_parity.py --out $OUT/full_parity.jsonl C3_suzanne:512 teapot:64 C5_part2_all:256 2> $OUT/full_parity.err | cut -c1-330
+run() { timeout -k 10 300 python3 $R/bench.py --steps $3 --warmup 1 --no-cpu-baseline --no-one-shot $2 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d.get('kernel_ms_per_step',{}); print('$1', 'ms', round(d['ms_per_step'],2), 'excl', round(d['schedule']['exclusive_pass_ms_per_step'],2), 'ext', round(k.get('ms_extend',0),2), 'shd', round(k.get('ms_shade',0),2), 'Mrays/s', round(d['value']))"; }
+echo "== wide / pair / wide5"
+for cfg in "--config C3_suzanne" "--config C5_part2_all --spp 256" "--config teapot --spp 256"; do
+  for i in 1 2; do
+    run "wide   $cfg" "$cfg" 3
+    FIREWORK_WIDE=0 run "pair   $cfg" "$cfg" 3
+    FIREWORK_LIB=$R/firework_amd/lib/variants/lib_wide5.so run "wide5  $cfg" "$cfg" 3
+  done
+done 2>&1 | tee $OUT/wide_ab.txt
+echo "== one-shot cold"
+FIREWORK_TRACE=1 timeout -k 10 200 python tools/oneshot.py 4 2>&1 | grep -v "^\[firework\] scene_create\|^\[firework\] render: enqueue" | tee $OUT/oneshot.txt | cut -c1-200
