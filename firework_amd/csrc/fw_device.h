@@ -84,7 +84,7 @@ struct DEnv {
     float color[3];
     float zenith[3];
     float horizon[3];
-    const float *hdr;      // equirect f32 RGB in HBM
+    const float *hdr;      // equirect map in HBM, 16 bytes per texel (r g b -)
     uint32_t hdr_w, hdr_h;
 };
 
@@ -248,6 +248,7 @@ void launch_scatter_tiles(hipStream_t stream, const uint32_t *ids, uint32_t n, c
                           uint8_t *out8, float *outg, float *outl);
 void launch_tile_order(hipStream_t stream, uint32_t width, uint32_t height, uint32_t *ids);
 void launch_upload(hipStream_t stream, const void *pinned_src, void *dst, size_t bytes);
+void preload_kernels();    // resolves every kernel of the default paths on the current device (a first launch pays ~2 ms for it otherwise)
 void launch_count_deposits(const LaunchCfg &, const uint32_t *dep_bits, uint32_t *total);
 void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out);
 void launch_selftest_libm(hipStream_t stream, int fn, uint32_t n, const float *x, const float *y, float *out);

@@ -2635,8 +2635,8 @@ __device__ V3 env_sample(const DEnv &e, V3 dir) {     // environment.rs:21-26,60
     unsigned long long idx = sat64((float)y * width) + x;
     unsigned long long n = (unsigned long long)e.hdr_w * e.hdr_h;
     if (idx >= n) idx = n - 1;     // the reference indexes out of bounds at the poles; clamp
-    const float *c = e.hdr + 3 * idx;
-    return mk(c[0], c[1], c[2]);
+    const float4 c = reinterpret_cast<const float4 *>(e.hdr)[idx];     // 16-byte texels (the host pads: fw_runtime.cpp)
+    return mk(c.x, c.y, c.z);
 }
 
 __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return v - 2.f * dot(v, n) * n; }           // util.rs:54-56
@@ -3464,6 +3464,20 @@ void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
 #undef FW_BOUNCE
 }
 #endif   // FW_AB
+void preload_kernels() {
+    hipFuncAttributes a;
+#define FW_TOUCH(k) (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k))
+    FW_TOUCH(k_raygen); FW_TOUCH(k_extend_linear); FW_TOUCH(k_extend_linear_defer); FW_TOUCH(k_extend_scan<true>); FW_TOUCH(k_extend_scan<false>);
+    FW_TOUCH(k_extend_tlas); FW_TOUCH(k_extend_tlas_park); FW_TOUCH(k_blas); FW_TOUCH(k_blas_lds<true>); FW_TOUCH(k_blas_lds<false>); FW_TOUCH(k_extend_tlas_lds);
+    FW_TOUCH((k_blas_wide<WIDE_F32, true>)); FW_TOUCH((k_blas_wide<WIDE_F32, false>)); FW_TOUCH((k_blas_wide<WIDE_Q8, true>)); FW_TOUCH((k_blas_wide<WIDE_Q8, false>));
+    FW_TOUCH(k_extend_tlas_wide); FW_TOUCH(k_extend_exact); FW_TOUCH(k_queue_totals); FW_TOUCH(k_count_deposits); FW_TOUCH(k_accumulate); FW_TOUCH(k_tile_order);
+    FW_TOUCH(k_resolve); FW_TOUCH(k_scatter_tiles);
+    FW_TOUCH((k_shade<0, 0, false>)); FW_TOUCH((k_shade<0, 0, true>)); FW_TOUCH((k_shade<0, 1, false>)); FW_TOUCH((k_shade<0, 1, true>));
+    FW_TOUCH((k_shade<1, 0, false>)); FW_TOUCH((k_shade<1, 0, true>)); FW_TOUCH((k_shade<1, 1, false>)); FW_TOUCH((k_shade<1, 1, true>));
+    FW_TOUCH((k_shade<2, 0, false>)); FW_TOUCH((k_shade<2, 0, true>)); FW_TOUCH((k_shade<2, 1, false>)); FW_TOUCH((k_shade<2, 1, true>));
+#undef FW_TOUCH
+    (void)hipGetLastError();
+}
 #ifdef FW_TRAV_STATS
 extern "C" int fw_debug_trav_stats(unsigned long long out[8]) {   // debug builds only; reads and clears the counters
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -39,7 +39,8 @@ struct Options {
     bool no_defer = false, no_hit4 = false, no_hoist = false, no_lds_tables = false, no_lds_trees = false, no_lds_tris = false, no_short_rays = false,
          no_tile_order = false, no_zero_skip = false, dep_pixel_major = false, dep_slot_major = false, trace = false, no_chain = false;
     int streams = 0;              // STREAMS=n batches in flight (0: the library's choice)
-    int soft_shear_log2 = 5, exact_shear_log2 = 10; double exact_far_x = 1024.0;   // SOFT_SHEAR_LOG2 (0: off), EXACT_SHEAR_LOG2, EXACT_FAR_X: the flag rules' thresholds (tools/flag_margin.py)
+    int soft_shear_log2 = 5, exact_shear_log2 = 10; double exact_far_x = 256.0;   // SOFT_SHEAR_LOG2 (0: off), EXACT_SHEAR_LOG2, EXACT_FAR_X: the flag rules' thresholds (tools/flag_margin.py)
+    double wide_node_cost = 0.0005;   // WIDE_NODE_COST: the constant a wide node costs in the collapse, in root areas (wide_convert)
     int wide = -1;                // WIDE=0|f32|q8: no wide nodes / force an encoding (-1: by size)
     long waves = 0;               // WAVES=n wave queues (0: the library's choice)
     long long paths_per_batch = 0;
@@ -49,7 +50,7 @@ struct Options {
 #endif
 };
 const char *const OPTION_NAMES[] = {"BVH", "NO_EXACT", "EXACT_ALL", "EXACT_FORM", "NO_DEFER", "NO_HIT4", "NO_HOIST", "NO_LDS_TABLES", "NO_LDS_TREES", "NO_LDS_TRIS",
-                                    "NO_SHORT_RAYS", "NO_TILE_ORDER", "NO_ZERO_SKIP", "DEP_PIXEL_MAJOR", "DEP_SLOT_MAJOR", "NO_CHAIN", "SOFT_SHEAR_LOG2", "EXACT_SHEAR_LOG2", "EXACT_FAR_X", "TRACE", "STREAMS", "WIDE", "WAVES",
+                                    "NO_SHORT_RAYS", "NO_TILE_ORDER", "NO_ZERO_SKIP", "DEP_PIXEL_MAJOR", "DEP_SLOT_MAJOR", "NO_CHAIN", "SOFT_SHEAR_LOG2", "EXACT_SHEAR_LOG2", "EXACT_FAR_X", "WIDE_NODE_COST", "TRACE", "STREAMS", "WIDE", "WAVES",
                                     "PATHS_PER_BATCH", "DUMP_PATH",
 #if FW_AB
                                     "FUSED", "TLAS_REFILL", "SHADE_LIST", "NO_SHADE_DEFER", "STAGGER",
@@ -77,7 +78,8 @@ bool option_apply(Options &o, const char *name, const char *v) {      // v == nu
     else if (n == "NO_CHAIN") o.no_chain = on();
     else if (n == "SOFT_SHEAR_LOG2") o.soft_shear_log2 = v ? (int)num() : 5;
     else if (n == "EXACT_SHEAR_LOG2") o.exact_shear_log2 = v ? (int)num() : 10;
-    else if (n == "EXACT_FAR_X") o.exact_far_x = v ? atof(v) : 1024.0;
+    else if (n == "EXACT_FAR_X") o.exact_far_x = v ? atof(v) : 256.0;
+    else if (n == "WIDE_NODE_COST") o.wide_node_cost = v ? atof(v) : 0.0005;
     else if (n == "TRACE") o.trace = on();
     else if (n == "STREAMS") o.streams = (int)std::max<long long>(0, num());
     else if (n == "WIDE") o.wide = !v ? -1 : (std::strcmp(v, "0") == 0 ? 0 : (std::strcmp(v, "f32") == 0 ? 1 : (std::strcmp(v, "q8") == 0 ? 2 : -1)));
@@ -207,12 +209,18 @@ std::vector<uint32_t> reference_ranks(const FlatBvh &ref, size_t n_items) {
 // to every hit that counts: tri_gate_ok / obj_gate_ok).  A triangle test carries (max|d| / |d_kz|) ulps of the distance from the ray's
 // origin to the triangle's far vertices — at most distance + extent — so a ray can "hit" a triangle it passes by that much: the part
 // in proportion to the distance is what the walks' relaxed exit planes admit (2^-12), the part in proportion to the extent is this.
-inline Box grown(const Box &b) {
-    const V3 e = b.mx - b.mn;
-    const float g = std::ldexp(std::fmax(std::fabs(e.x), std::fmax(std::fabs(e.y), std::fabs(e.z))), -14);
+// How much: an item test's error SIDEWAYS, for a ray that runs along a face of the box, is not helped by relaxed exit planes and has to
+// be in the box itself (part2 pixel 1049389, sample 106: a camera ray 17 units away grazes a sphere of radius 0.1 past the face of its
+// own box, gpurun_out/r04j).  Every ray that is not on the exact list starts within far_r = 256 x the smallest item (DExact.far_r):
+//   triangle: shear x 2^-24 x distance, shear < 2^10 (beyond: the exact list) -> 2^-14 far_r = 2^-6 of a typical triangle of the mesh;
+//   sphere / cone / cylinder: the discriminant's rounding lets a ray that misses by 2^-24 L^2 / r still hit -> 2^-22 far_r^2 / size;
+//   rectangles and boxes: their tests are exact in the plane; 2^-14 of the extent for the rounding of the slab test itself.
+inline float box_extent(const Box &b) { const V3 e = b.mx - b.mn; return std::fmax(std::fabs(e.x), std::fmax(std::fabs(e.y), std::fabs(e.z))); }
+inline Box grown_by(const Box &b, float g) {
     if (!(g > 0.f) || !std::isfinite(g)) return b;
     return Box{{b.mn.x - g, b.mn.y - g, b.mn.z - g}, {b.mx.x + g, b.mx.y + g, b.mx.z + g}};
 }
+inline Box grown(const Box &b) { return grown_by(b, std::ldexp(box_extent(b), -14)); }
 
 // item boxes := the box of the reference leaf node that holds the item (its own box for a Leaf, the union for a DoubleLeaf)
 void leaf_node_boxes(const FlatBvh &ref, std::vector<Box> &boxes) {
@@ -369,7 +377,7 @@ struct WideChild { bool leaf; uint32_t id; Box box; };   // id: item, or node in
 // nodes of two leaves (suzanne: 458 nodes for 968 triangles, teapot 3 116 for 6 320: 150 KB quantised, too big for a CU's LDS).
 struct BinNode { int left = -1, right = -1; uint32_t item = 0; Box box{}; float cost[5] = {0, 0, 0, 0, 0}; uint8_t split[5] = {0, 0, 0, 0, 0}; bool inherit[5] = {false, false, false, false, false}; };
 constexpr float WIDE_COST_STEP = 1.0f, WIDE_COST_ITEM = 0.7f;     // one wide step (four boxes, a stack operation) against one item test
-static int bin_build(const FlatBvh &src, uint32_t i, const std::vector<Box> &item_boxes, std::vector<BinNode> &t) {
+static int bin_build(const FlatBvh &src, uint32_t i, const std::vector<Box> &item_boxes, std::vector<BinNode> &t, float node_cost) {
     const float *nd = &src.nodes[(size_t)i * 8];
     uint32_t A, B; std::memcpy(&A, nd + 3, 4); std::memcpy(&B, nd + 7, 4);
     const uint32_t kind = A >> 30;
@@ -377,7 +385,7 @@ static int bin_build(const FlatBvh &src, uint32_t i, const std::vector<Box> &ite
     if (kind == fw::NODE_LEAF) return leaf(A & fw::NODE_MASK);
     BinNode n;
     if (kind == fw::NODE_DOUBLE) { n.left = leaf(A & fw::NODE_MASK); n.right = leaf(B); }
-    else { n.left = bin_build(src, i + 1, item_boxes, t); n.right = bin_build(src, A & fw::NODE_MASK, item_boxes, t); }
+    else { n.left = bin_build(src, i + 1, item_boxes, t, node_cost); n.right = bin_build(src, A & fw::NODE_MASK, item_boxes, t, node_cost); }
     const BinNode &l = t[n.left], &r = t[n.right];
     n.box = box_union(l.box, r.box);
     float dist[5] = {0, 0, 0, 0, 0};
@@ -385,7 +393,7 @@ static int bin_build(const FlatBvh &src, uint32_t i, const std::vector<Box> &ite
         dist[k] = 3.0e38f;
         for (int j = 1; j < k; j++) { const float c = l.cost[j] + r.cost[k - j]; if (c < dist[k]) { dist[k] = c; n.split[k] = (uint8_t)j; } }
     }
-    n.cost[1] = box_area(n.box) * WIDE_COST_STEP + dist[4];
+    n.cost[1] = box_area(n.box) * WIDE_COST_STEP + node_cost + dist[4];
     for (int k = 2; k <= 4; k++) { n.inherit[k] = !(dist[k] < n.cost[k - 1]); n.cost[k] = n.inherit[k] ? n.cost[k - 1] : dist[k]; }
     t.push_back(n);
     return (int)t.size() - 1;
@@ -409,6 +417,7 @@ static bool wide_quantise_axis(const float *lo, const float *hi, int n, float or
     for (int c = 0; c < n; c++) { if (!(lo[c] >= org) || !(hi[c] >= lo[c]) || !std::isfinite(hi[c])) return false; ext = std::fmax(ext, hi[c] - org); }
     int e = 1;                                               // smallest scale with every plane <= 254 quanta from the origin (255 is kept for the rounding step)
     if (ext > 0.f) { int ex; std::frexp(ext / 254.f, &ex); e = std::max(1, std::min(254, ex + 127)); }
+    if (org != 0.f) { int eo; std::frexp(std::fabs(org), &eo); e = std::max(e, std::min(254, eo + 127 - 22)); }   // a quantum the origin can see: 255 quanta must move it (a free slot's inverted box)
     for (; e <= 254; e++) {
         const float s = bits_f((uint32_t)e << 23);
         bool ok = true;
@@ -481,7 +490,11 @@ static uint32_t wide_convert(const FlatBvh &src, const std::vector<Box> &item_bo
     const uint32_t base = out.count();
     std::vector<BinNode> bin;
     bin.reserve(2 * item_boxes.size());
-    const int root = bin_build(src, 0, item_boxes, bin);
+    // a node also costs LDS: a constant per node (WIDE_COST_NODE of the root's area) makes the collapse prefer full nodes where the
+    // surface-area terms are indifferent (teapot: 2 453 -> FILL nodes, which is what lets sixteen waves' stacks fit beside them)
+    const float *rn = &src.nodes[0];
+    const float node_cost = (float)options().wide_node_cost * box_area(Box{{rn[0], rn[1], rn[2]}, {rn[4], rn[5], rn[6]}});
+    const int root = bin_build(src, 0, item_boxes, bin, node_cost);
     const uint32_t r = wide_build_rec(bin, root, local, base, 0);
     if (r == 0xffffffffu) return r;
     out.words.insert(out.words.end(), local.words.begin(), local.words.end());
@@ -530,13 +543,17 @@ static uint32_t wide_check(const WideBvh &t, uint32_t root, const std::vector<Bo
         }
         for (int c = 0; c < 4; c++) {
             const bool is_free = c > 0 && r[c] == r[0];
-            if (is_free) { free_slots++; if (!(dec[c].mn.x > dec[c].mx.x && dec[c].mn.y > dec[c].mx.y && dec[c].mn.z > dec[c].mx.z)) bad++; continue; }
+            if (is_free) { free_slots++; if (!(dec[c].mn.x > dec[c].mx.x && dec[c].mn.y > dec[c].mx.y && dec[c].mn.z > dec[c].mx.z)) { bad++; if (getenv("FW_WIDE_DEBUG")) fprintf(stderr, "node %u free slot %d hittable\n", rec.node, c); } continue; }
             const Box exact = subtree_box(subtree_box, r[c]);
             if (!(dec[c].mn.x <= exact.mn.x && dec[c].mn.y <= exact.mn.y && dec[c].mn.z <= exact.mn.z &&
-                  dec[c].mx.x >= exact.mx.x && dec[c].mx.y >= exact.mx.y && dec[c].mx.z >= exact.mx.z)) bad++;
+                  dec[c].mx.x >= exact.mx.x && dec[c].mx.y >= exact.mx.y && dec[c].mx.z >= exact.mx.z)) {
+                bad++;
+                if (getenv("FW_WIDE_DEBUG")) fprintf(stderr, "node %u child %d ref %x: dec [%g %g %g | %g %g %g] exact [%g %g %g | %g %g %g]\n", rec.node, c, r[c], dec[c].mn.x, dec[c].mn.y, dec[c].mn.z,
+                                                      dec[c].mx.x, dec[c].mx.y, dec[c].mx.z, exact.mn.x, exact.mn.y, exact.mn.z, exact.mx.x, exact.mx.y, exact.mx.z);
+            }
             if (t.fmt == fw::WIDE_F32 && (r[c] & fw::W_LEAF) && std::memcmp(&dec[c], &item_boxes[r[c] & 0x7fffu], sizeof(Box)) != 0) bad++;   // an item's own box, bit for bit
-            if (r[c] & fw::W_LEAF) { const uint32_t it = r[c] & 0x7fffu; if (it >= seen.size() || seen[it]++) bad++; leaves++; }
-            else { if (r[c] <= rec.node) bad++; todo.push_back({r[c], Box{}, false}); }
+            if (r[c] & fw::W_LEAF) { const uint32_t it = r[c] & 0x7fffu; if (it >= seen.size() || seen[it]++) { bad++; if (getenv("FW_WIDE_DEBUG")) fprintf(stderr, "node %u child %d: item %u seen twice or out of range\n", rec.node, c, it); } leaves++; }
+            else { if (r[c] <= rec.node) { bad++; if (getenv("FW_WIDE_DEBUG")) fprintf(stderr, "node %u child %d: backward reference %u\n", rec.node, c, r[c]); } todo.push_back({r[c], Box{}, false}); }
         }
     }
     for (uint32_t s : seen) if (s != 1) bad++;
@@ -656,11 +673,13 @@ void warm_device(int dev) {
     if (!ws->staging && hipHostMalloc(&ws->staging, 1 << 20, hipHostMallocDefault) == hipSuccess) ws->staging_bytes = 1 << 20;
     if (!ws->upload_stream && hipStreamCreateWithFlags(&ws->upload_stream, hipStreamNonBlocking) != hipSuccess) ws->upload_stream = nullptr;
     if (!ws->ev_upload && hipEventCreateWithFlags(&ws->ev_upload, hipEventDisableTiming) != hipSuccess) ws->ev_upload = nullptr;
+    for (int l = 0; l < 2; l++) if (!ws->lanes[l].stream && hipStreamCreateWithFlags(&ws->lanes[l].stream, hipStreamNonBlocking) != hipSuccess) ws->lanes[l].stream = nullptr;
     if (!ws->staging || !ws->upload_stream) return;
     void *tmp = nullptr;
     if (hipMalloc(&tmp, 256) != hipSuccess) return;
     std::memset(ws->staging, 0, 256);
     fw::launch_upload(ws->upload_stream, ws->staging, tmp, 256);          // any launch loads the code objects of the whole library on this device
+    fw::preload_kernels();                                                // ... and every kernel's first launch resolves it: 60 ms of a first frame's enqueue (gpurun_out/r04j)
     if (ws->ev_upload) (void)hipEventRecord(ws->ev_upload, ws->upload_stream);
     (void)hipStreamSynchronize(ws->upload_stream);
     (void)hipGetLastError();
@@ -846,7 +865,10 @@ struct Flattener {
                 g[0] = gboxes[t].mn.x; g[1] = gboxes[t].mn.y; g[2] = gboxes[t].mn.z; g[4] = gboxes[t].mx.x; g[5] = gboxes[t].mx.y; g[6] = gboxes[t].mx.z;
             }
         }
-        for (Box &b : boxes) b = grown(b);                    // from here on: the boxes of the walked trees
+        {   // from here on: the boxes of the walked trees (grown_by: 2^-6 of a typical triangle, at least 2^-14 of the triangle's own extent)
+            const float typ = box_extent(sp.box) / std::sqrt((float)std::max(1u, n_tris));
+            for (Box &b : boxes) b = grown_by(b, std::fmax(std::ldexp(typ, -6), std::ldexp(box_extent(b), -14)));
+        }
         if (use_sah()) { FlatBvh sah; sah_build(sah, boxes); local = std::move(sah); }
         uint32_t root = pair_convert(local, boxes, blas);     // root reference into the shared BLAS array
         blas_depth = blas.depth;
@@ -1005,7 +1027,16 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
             if ((kf >> 8) & fw::OF_GATE) build_boxes[items[q]] = own_boxes[items[q]] = box_union(node_box, true_world[items[q]]);
         }
     }
-    for (Box &b : build_boxes) b = grown(b);                     // the walked trees' boxes (grown(): what a walk must still reach)
+    for (uint32_t i = 0; i < desc->n_objects; i++) {             // the walked trees' boxes (grown_by: what a walk must still reach)
+        uint32_t kf; std::memcpy(&kf, &objs[(size_t)i * fw::OBJ_Q * 4 + 3], 4);
+        const uint32_t kind = kf & 0xffu, inner = kf >> 24, shape = kind == FW_SHAPE_CONSTANT_MEDIUM ? inner : kind;
+        const float ext = box_extent(build_boxes[i]);
+        float g = std::ldexp(ext, -14);
+        if (shape == FW_SHAPE_TRIANGLE_MESH) g = std::fmax(g, std::ldexp(obj_size[i], -5));                        // its triangles' boxes grew by 2^-6 of this, in the mesh's frame
+        else if ((shape == FW_SHAPE_SPHERE || shape == FW_SHAPE_CONE || shape == FW_SHAPE_CYLINDER) && (ex.mode & 2u) && ext > 0.f)
+            g = std::fmax(g, std::fmin(ext, std::ldexp(ex.far_r * ex.far_r / ext, -22)));
+        build_boxes[i] = grown_by(build_boxes[i], g);
+    }
     auto pack_boxes = [&](const std::vector<Box> &bs) {
         std::vector<float> out((size_t)desc->n_objects * 8, 0.f);
         for (uint32_t i = 0; i < desc->n_objects; i++) {
@@ -1147,7 +1178,9 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         {fl.tri.data(), fl.tri.size() * 4, 0}, {fl.any_attr ? fl.tri_attr.data() : nullptr, fl.any_attr ? fl.tri_attr.size() * 4 : 0, 0},
         {fl.tri_rank.data(), fl.tri_rank.size() * 4, 0}, {obj_rank.data(), obj_rank.size() * 4, 0}, {gate.data(), gate.size() * 4, 0},
         {mats.data(), mats.size() * 4, 0}, {texs.data(), texs.size() * 4, 0}, {images.data(), images.size(), 0},
-        {e.kind == FW_ENV_HDR ? e.hdr_rgb : nullptr, e.kind == FW_ENV_HDR ? (size_t)e.hdr_w * e.hdr_h * 3 * 4 : 0, 0},
+        // the HDR map as 16-byte texels (rgb + pad), written straight into the blob below: a 12-byte texel straddles a 32-byte
+        // sector in two offsets of eight, and a miss's lookup is one gather per path out of 100 MB
+        {nullptr, e.kind == FW_ENV_HDR ? (size_t)e.hdr_w * e.hdr_h * 4 * 4 : 0, 0},
         {cull.data(), cull.size() * 4, 0},
         {ref_tlas.data(), ref_tlas.size() * 4, 0}, {fl.ref_blas.data(), fl.ref_blas.size() * 4, 0}, {obj_ref_blas.data(), obj_ref_blas.size() * 4, 0},
         {leafb.data(), leafb.size() * 4, 0},
@@ -1176,7 +1209,12 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     size_t prev_end = 0;
     for (const Sec &x : secs) {       // sections + zeroed padding between them
         if (x.off > prev_end) std::memset(blob + prev_end, 0, x.off - prev_end);
-        if (x.bytes) std::memcpy(blob + x.off, x.src, x.bytes);
+        if (&x == &secs[11] && x.bytes) {
+            float *dst = reinterpret_cast<float *>(blob + x.off);
+            const float *src = e.hdr_rgb;
+            for (size_t k = 0, n = (size_t)e.hdr_w * e.hdr_h; k < n; k++) { dst[4 * k] = src[3 * k]; dst[4 * k + 1] = src[3 * k + 1]; dst[4 * k + 2] = src[3 * k + 2]; dst[4 * k + 3] = 0.f; }
+        }
+        else if (x.bytes) std::memcpy(blob + x.off, x.src, x.bytes);
         prev_end = x.off + x.bytes;
     }
     if (total > prev_end) std::memset(blob + prev_end, 0, total - prev_end);
@@ -1335,6 +1373,11 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     if (paths64 > 0x7fffffffull) return fail(FW_ERR_UNSUPPORTED, "too many paths per batch");
     uint32_t max_paths = (uint32_t)paths64;
     uint32_t n_batches = (p->samples + spp_b - 1) / spp_b;
+    // equal batches (round 4): 512 samples at up to 145 per batch were 145 + 145 + 145 + 77; four times 128 keep the two lanes level, and the
+    // pools — sized by the largest batch, with a power of two of chunks per wave — shrink with it (suzanne: 73 -> 37 GB; the arena no longer
+    // has to grow between cornell and suzanne: hipFree of a 35 GB arena cost 2.4 s of the caller's time)
+    spp_b = (p->samples + n_batches - 1) / n_batches;
+    max_paths = n_pix * spp_b;
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, n_batches);
 
     // wave-private queues: many more waves than are resident, each owning >= 8 chunks of 64 paths when the batch allows
@@ -1346,6 +1389,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     const uint32_t unit = (uint32_t)sc->n_cus * 4u * (p->use_bvh ? 20u : 28u);
     const uint64_t chunks = ((uint64_t)max_paths + 63u) / 64u;
     uint32_t want_waves = unit * (uint32_t)std::min<uint64_t>(3u, std::max<uint64_t>(1u, chunks / ((uint64_t)unit * 16u)));
+    // Round 4 (gpurun_out/r04i/share_waves.txt, r04j/cornell_waves.txt): with TWO batches in flight on a linear scene (the box lists: cornell)
+    // fewer, longer queues overlap better — whole frame 86 016 waves 36.4-37.0 ms, 28 672: 35.2-35.3 (its exclusive pass is slower: 40.6 vs
+    // 37.8) — and a small share keeps its queues long with 12 288: rank 0's eighth of the frame 5.9 -> 5.5 ms (79 -> 85 % of ideal).
+    if (!p->use_bvh && n_lanes > 1) want_waves = chunks >= (1u << 20) ? unit : (uint32_t)sc->n_cus * 48u;
     if (O.waves > 0) want_waves = (uint32_t)O.waves;
     q.n_waves = std::max(4u, std::min(want_waves, (max_paths + 511u) / 512u));
     q.n_waves = (q.n_waves + 3u) & ~3u;
@@ -1390,7 +1437,14 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         return off;
     };
     {
-        const size_t want = (layout(nullptr) + ((size_t)1 << 30) - 1) & ~(((size_t)1 << 30) - 1);
+        size_t want = (layout(nullptr) + ((size_t)1 << 30) - 1) & ~(((size_t)1 << 30) - 1);
+        if (want > ws->arena.bytes) {
+            // growing means hipFree + hipMalloc of tens of GB: 2.8 s for 35 -> 36 GiB (gpurun_out/r04j/oneshot.txt), while the allocation itself is
+            // lazy and costs 0.4 ms.  So the arena is made once, big enough for every default-budget frame (the largest config's pools are 52 GB),
+            // memory permitting, and grows only past that.
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::max(want, std::min<size_t>((size_t)64 << 30, (free_b + ws->arena.bytes) / 3));
+        }
         const auto ta = std::chrono::steady_clock::now();
         const bool grow = want > ws->arena.bytes;
         need(ws->arena, want);
