@@ -717,6 +717,9 @@ __device__ __forceinline__ bool hit_aabb_entry(float4 lo, float4 hi, V3 o, V3 in
 //             box decides (tri_gate, 32 B from HBM: flat axis-aligned triangles, and one other hit in ~1e7);
 //   object:   its reference leaf-node box (obj_gate), fetched with the object record.
 __device__ __forceinline__ bool tri_gate_ok(const DScene &sc, size_t tri, V3 p0, V3 p1, V3 p2, V3 o, V3 inv, float tmin, float tmax) {
+#ifdef FW_AB_NO_VERIFY      // timing variant only (tools/build_variant.sh noverify -DFW_AB_NO_VERIFY): what the rule costs
+    return true;
+#endif
     // Sufficient, and all that nearly every hit needs: the box of the three vertices WITHOUT mesh.rs:230-241's padding of flat axes,
     // entry = the smaller and exit = the larger of an axis' two plane distances.  With lo <= hi the smaller IS the plane the
     // reference picks by the sign of 1/d (the slab arithmetic is monotone; a NaN distance — the origin in a plane it runs along —
@@ -970,10 +973,11 @@ __device__ __forceinline__ bool hit_mesh_exact_wave(const DScene &sc, uint32_t r
 
 // shape dispatch in object space.  prim: rect3d face / mesh triangle, else 0.  EXACT: a mesh takes the literal reference walk
 // and aux0 is its reference tree's first node (k_extend_exact; 1: one ray per lane, 2: per wave).
-template <int EXACT = 0>
+template <int EXACT = 0, bool MESH = true>
 __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float4 q3, float4 q4, uint32_t aux0, uint32_t aux1,
                                           const Ray &r, float tmin, float tmax, uint32_t *stack_base, float &t, uint32_t &prim) {
     prim = 0;
+    if (!MESH && kind == 5u) return false;     // the caller's scene holds no mesh (the host checks): the walk is compiled out
     switch (kind) {
     case 0: return hit_sphere(q3.x, r, tmin, tmax, t);
     case 1: case 2: case 3: return hit_rect_kind(kind, q3, q4, r, tmin, tmax, t);
@@ -1012,15 +1016,15 @@ __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const
 
 // RenderObjectInternal::hit up to the object-space t (the world-space point/normal are rebuilt in k_shade)
 // MEDIUM = false: the caller's scene holds no ConstantMedium (k_extend_linear_defer: the host checks), so the medium's code —
-// its double-precision log10 costs registers even where it never runs — is compiled out
-template <bool MEDIUM = true, int EXACT = 0>
+// its double-precision log10 costs registers even where it never runs — is compiled out; MESH = false likewise for the mesh walk
+template <bool MEDIUM = true, int EXACT = 0, bool MESH = true>
 __device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint32_t obj_index, const Ray &world, float tmin,
                                            float tmax, uint32_t *stack_base, const RngKey &key, uint32_t segment, float &t, uint32_t &prim) {
     Ray r = to_object_space(o, world);
     uint32_t kind = obj_kind(o);
     if (MEDIUM && kind == 6) { prim = 0; return hit_medium<EXACT>(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
     const uint32_t root = (EXACT && kind == 5u) ? sc.obj_ref_blas[obj_index] : o.aux0;
-    return hit_shape<EXACT>(sc, kind, o.q3, o.q4, root, o.aux1, r, tmin, tmax, stack_base, t, prim);
+    return hit_shape<EXACT, MESH>(sc, kind, o.q3, o.q4, root, o.aux1, r, tmin, tmax, stack_base, t, prim);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1587,9 +1591,17 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVE
 // sees exactly the sequence of exact tests of scene.rs:137-149 minus tests that cannot succeed: the bits do not change.
 // (Round 2's first attempt kept one list with a shape mask per ray and lost, 19.2 -> 24.4 ms: per-lane object records in
 // the run phase, 18 spills.  One list per object keeps the records scalar.)
-// Dynamic LDS per wave: list 0: DEFER0_CAP entries, list 1: DEFER1_CAP entries, 12 bytes each.
+// Dynamic LDS per wave: two lists of 64 entries, DEFER_FIELDS dwords each (round 4, below).
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t DEFER0_CAP = 128, DEFER1_CAP = 192;     // between two runs list 0 grows by <= 64 (one chunk), list 1 by <= 64 (the chunk) + <= 64 (list 0's run)
+// Round 4: a list entry CARRIES ITS RAY.  Until then an entry was (slot, t, code) and the run gathered the ray again by slot — 24 useful
+// bytes in two sectors, from beyond L2: the kernel's PMC traffic was 2.16 x its algorithmic bytes, and a timing build that skipped the
+// gather (wrong frames) rendered cornell in 33.6 instead of 37.0 ms (gpurun_out/r04m/norefetch.txt: k_extend 17.1 -> 14.8 ms and k_shade,
+// which shares HBM with it when two batches overlap, 19.8 -> 18.3).  Cache tricks did not get it back (non-temporal queue stores, earlier
+// runs, fewer resident waves: gpurun_out/r04n).  With the ray in the entry — 36 bytes — the old lists (128 + 192 entries, sized for a run
+// of exactly 64) would take 11.5 KB per wave: three waves per SIMD for a kernel whose division chains want eight.  So a list holds 64
+// entries and never overflows (make_room, below): 2 x 64 x 36 B = 4.6 KB per wave, 147 KB at eight waves per SIMD.  The price: a run
+// has 65 - (one chunk's candidates) to 64 of its lanes busy instead of all of them.
+constexpr uint32_t DEFER_FIELDS = 9;       // slot | later-list bit 31, t, code, origin.xyz, direction.xyz — [field][64] per list
 extern __shared__ uint32_t lds_defer[];
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_DEFER_WAVES, 8)))
 void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, uint32_t n_def) {
@@ -1598,45 +1610,63 @@ void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ 
     const uint32_t n = q.wcount[(size_t)segment * q.n_waves + w], base = w * q.cap;
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
     const uint32_t n_first = sc.n_objects - n_def;
-    uint32_t *l_slot[2] = {lds_defer, lds_defer + 3 * DEFER0_CAP};
-    uint32_t cap_[2] = {DEFER0_CAP, DEFER1_CAP};
-    // entry e of list d: [slot | later-list bit 31][t][code]
-    auto E = [&](uint32_t d, uint32_t e, uint32_t field) -> uint32_t & { return l_slot[d][field * cap_[d] + e]; };
+    uint32_t *const L0 = lds_defer, *const L1 = lds_defer + DEFER_FIELDS * 64u;
     uint32_t cnt0 = 0, cnt1 = 0;
     const RngKey nokey{0, 0, 0};
     auto write_final = [&](uint32_t slot, float t, uint32_t code) {
         if (f.hit4) reinterpret_cast<uint32_t *>(hits)[slot] = code; else qst(&hits[slot], make_float2(t, __uint_as_float(code)));
     };
-    auto append = [&](uint32_t d, bool want, uint32_t slot_bits, float t, uint32_t code) {
+    auto put = [&](uint32_t *L, uint32_t e, uint32_t sb, float t, uint32_t code, const Ray &r) {
+        L[e] = sb; L[64u + e] = __float_as_uint(t); L[128u + e] = code;
+        L[192u + e] = __float_as_uint(r.o.x); L[256u + e] = __float_as_uint(r.o.y); L[320u + e] = __float_as_uint(r.o.z);
+        L[384u + e] = __float_as_uint(r.d.x); L[448u + e] = __float_as_uint(r.d.y); L[512u + e] = __float_as_uint(r.d.z);
+    };
+    auto get = [&](const uint32_t *L, uint32_t e, uint32_t &sb, float &t, uint32_t &code, Ray &r) {
+        sb = L[e]; t = __uint_as_float(L[64u + e]); code = L[128u + e];
+        r.o = mk(__uint_as_float(L[192u + e]), __uint_as_float(L[256u + e]), __uint_as_float(L[320u + e]));
+        r.d = mk(__uint_as_float(L[384u + e]), __uint_as_float(L[448u + e]), __uint_as_float(L[512u + e]));
+    };
+    // the exact test of deferred object d for the first `take` entries of its list, one per lane, the object record wave-uniform
+    auto test = [&](uint32_t d, const Ray &r, float &t, uint32_t &code) {
+        const uint32_t k = n_first + d;
+        const Obj o = load_obj(sc.obj, k);                            // scalar loads
+        float tt; uint32_t prim;
+        if (hit_rect3d(o.q3, o.q4, to_object_space(o, r), TMIN, t, tt, prim)) { t = tt; code = (k << sc.prim_bits) | prim; }   // a plain Rect3d (the host checks)
+    };
+    // Lists never overflow: before a chunk appends its candidates, make_room runs whichever list could not take them (and list 1 first when
+    // it could not take what list 0's run passes on — the entries flagged in bit 31, counted beforehand).  A run so has between
+    // 65 - (the chunk's candidates) and 64 lanes busy.  One textual copy of each run: the two places list 1 may have to run are the two
+    // trips of a loop.
+    auto append = [&](uint32_t *L, uint32_t &cnt, bool want, uint32_t sb, float t, uint32_t code, const Ray &r) {
         const unsigned long long m = __ballot(want);
         if (!m) return;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        uint32_t &cnt = d == 0 ? cnt0 : cnt1;
-        if (want) { const uint32_t e = cnt + rank; E(d, e, 0) = slot_bits; E(d, e, 1) = __float_as_uint(t); E(d, e, 2) = code; }
+        if (want) put(L, cnt + rank, sb, t, code, r);
         cnt += (uint32_t)__popcll(m);
     };
-    // The exact test of deferred object d for up to 64 listed rays (one per lane).  The rays are gathered again by slot
-    // (L2-warm).  (Requesting them one chunk ahead, across the in-line work, costs 12 registers: 80 with 8 spills, 18.6 vs
-    // 18.4 ms.)
-    auto run = [&](uint32_t d, uint32_t take) {
-        uint32_t &cnt = d == 0 ? cnt0 : cnt1;
-        const uint32_t e = cnt - take + lane;
-        const bool on = lane < take;
-        uint32_t sb = 0, code = MISS; float t = TMAX;
-        if (on) { sb = E(d, e, 0); t = __uint_as_float(E(d, e, 1)); code = E(d, e, 2); }
-        cnt -= take;
-        const uint32_t slot = sb & 0x7fffffffu;
-        if (on) {
-            const float4 ra = qld(&in.ray_a[slot]); const float2 rb = load_ray_b(in, slot, f, segment);
-            const Ray r = make_ray(ra, rb, f, segment);
-            const uint32_t k = n_first + d;
-            const Obj o = load_obj(sc.obj, k);                        // wave-uniform: scalar loads
-            float tt; uint32_t prim;
-            if (hit_object<false>(sc, o, k, r, TMIN, t, nullptr, nokey, segment, tt, prim)) { t = tt; code = (k << sc.prim_bits) | prim; }
+    // need0 / need1: entries the caller is about to append to list 0 / list 1 (65: run whatever is there — the end of the queue)
+    auto make_room = [&](uint32_t need0, uint32_t need1) {
+        const bool r0 = cnt0 != 0u && cnt0 + need0 > 64u;
+        const uint32_t pass_on = r0 ? (uint32_t)__popcll(__ballot(lane < cnt0 && (L0[lane] >> 31) != 0u)) : 0u;
+#pragma nounroll
+        for (int phase = 0; phase < 2; phase++) {
+            const bool r1 = cnt1 != 0u && (phase == 0 ? cnt1 + pass_on > 64u : cnt1 + need1 > 64u);
+            if (r1) {
+                uint32_t sb = 0, code = MISS; float t = TMAX; Ray r{mk(0, 0, 0), mk(0, 0, 1)};
+                if (lane < cnt1) { get(L1, lane, sb, t, code, r); test(1, r, t, code); write_final(sb, t, code); }
+                cnt1 = 0;
+            }
+            if (phase == 0 && r0) {
+                uint32_t sb = 0, code = MISS; float t = TMAX; Ray r{mk(0, 0, 0), mk(0, 0, 1)};
+                const bool on = lane < cnt0;
+                if (on) { get(L0, lane, sb, t, code, r); test(0, r, t, code); }
+                cnt0 = 0;
+                const bool more = on && (sb >> 31) != 0u;              // listed for the second box too
+                const uint32_t slot = sb & 0x7fffffffu;
+                if (on && !more) write_final(slot, t, code);
+                append(L1, cnt1, more, slot, t, code, r);
+            }
         }
-        const bool more = on && (sb >> 31) != 0u;                      // only list 0 entries can carry it
-        if (d == 0) append(1, more, slot, t, code);
-        if (on && !more) write_final(slot, t, code);
     };
     float4 ra_n = make_float4(0, 0, 0, 0); float2 rb_n = make_float2(0, 0);
     if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); }
@@ -1647,13 +1677,13 @@ void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ 
         const bool active = j < n;
         float best_t = TMAX; uint32_t best_obj = MISS, best_prim = 0;
         bool may0 = false, may1 = false;
+        const Ray r = make_ray(ra, rb, f, segment);
         if (active) {
-            const Ray r = make_ray(ra, rb, f, segment);
             const float4 *op = sc.obj;
             for (uint32_t k = 0; k < n_first; k++, op += OBJ_Q) {
                 const Obj o = load_obj(op, 0);
                 float t; uint32_t prim;
-                if (hit_object<false>(sc, o, k, r, TMIN, best_t, nullptr, nokey, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+                if (hit_object<false, 0, false>(sc, o, k, r, TMIN, best_t, nullptr, nokey, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
             }
             // conservative pre-tests (see closest_hit's segment-0 cull: approximate reciprocals, boxes inflated by 1e-4 of the
             // scene and ray-origin scale, NaN-dropping min/max), here per lane and also culled against the hit so far
@@ -1674,14 +1704,13 @@ void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ 
             }
         }
         const uint32_t code = best_obj == MISS ? MISS : ((best_obj << sc.prim_bits) | best_prim);
-        append(0, may0, i | (may1 ? 0x80000000u : 0u), best_t, code);
-        append(1, may1 && !may0, i, best_t, code);
+        const bool c1 = may1 && !may0;                                  // straight to list 1; a ray listed for box 0 carries box 1 in bit 31
+        make_room((uint32_t)__popcll(__ballot(may0)), (uint32_t)__popcll(__ballot(c1)));
         if (active && !may0 && !may1) write_final(i, best_t, code);
-        if (cnt0 >= 64u) run(0, 64u);                                 // <= 64 more entries for list 1
-        while (cnt1 >= 64u) run(1, 64u);
+        append(L0, cnt0, may0, i | (may1 ? 0x80000000u : 0u), best_t, code, r);
+        append(L1, cnt1, c1, i, best_t, code, r);
     }
-    while (cnt0) run(0, min(cnt0, 64u));
-    while (cnt1) run(1, min(cnt1, 64u));
+    make_room(65u, 65u);
 }
 
 // (The first attempt of round 2 to DEFER the expensive shapes of the linear scan — k_extend_linear_defer above is the second: cornell's two rotated boxes are 12 of a ray's 18 rectangle
@@ -2151,6 +2180,9 @@ __device__ __forceinline__ void stage_lds(uint32_t *__restrict__ dst, const uint
     for (uint32_t k = threadIdx.x; k < dwords / 4u; k += blockDim.x) reinterpret_cast<uint4 *>(dst)[k] = reinterpret_cast<const uint4 *>(src)[k];
 }
 constexpr int WIDE_MAX_WAVES = 16;
+#ifndef FW_WIDE_TWO_STEPS
+#define FW_WIDE_TWO_STEPS 1     // a second step per exit check: suzanne 69.4 -> 67.1 ms, teapot @256 100 -> 98.3 (gpurun_out/r04m)
+#endif
 #ifndef FW_WIDE_WAVES
 #define FW_WIDE_WAVES 4     // register budget of k_blas_wide (waves per SIMD it must leave room for): its own 16 waves per CU are 4 per SIMD; what is
 #endif                      // left of the register file is where the other batch's kernels run
@@ -2236,6 +2268,9 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
             if (walking) cur = wide_step<FMT>(lds_w, cur, ro, inv, relaxed(inv), sel, box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+#if FW_WIDE_TWO_STEPS       // a second step per exit check (k_blas_lds gained 2 % from it on pair nodes)
+            if (act && !(cur & W_LEAF)) cur = wide_step<FMT>(lds_w, cur, ro, inv, relaxed(inv), sel, box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+#endif
         }
         // The round's triangle tests: the one put aside, then the one held.  A hit that would become the ray's best is a CANDIDATE; the
         // reference's gating rule (tri_gate_ok) is applied once per round, to the nearer of the two, and to the other only if that one
@@ -3413,7 +3448,7 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
 #if FW_AB
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 #endif
-    else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)(DEFER0_CAP + DEFER1_CAP) * 12, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
+    else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)2 * 64 * DEFER_FIELDS * 4, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
 void launch_extend_exact(const LaunchCfg &c, const DScene &sc, const DFrame &f, const DPaths &in, float2 *hits, int segment, bool use_bvh) {

@@ -543,17 +543,13 @@ static uint32_t wide_check(const WideBvh &t, uint32_t root, const std::vector<Bo
         }
         for (int c = 0; c < 4; c++) {
             const bool is_free = c > 0 && r[c] == r[0];
-            if (is_free) { free_slots++; if (!(dec[c].mn.x > dec[c].mx.x && dec[c].mn.y > dec[c].mx.y && dec[c].mn.z > dec[c].mx.z)) { bad++; if (getenv("FW_WIDE_DEBUG")) fprintf(stderr, "node %u free slot %d hittable\n", rec.node, c); } continue; }
+            if (is_free) { free_slots++; if (!(dec[c].mn.x > dec[c].mx.x && dec[c].mn.y > dec[c].mx.y && dec[c].mn.z > dec[c].mx.z)) bad++; continue; }
             const Box exact = subtree_box(subtree_box, r[c]);
             if (!(dec[c].mn.x <= exact.mn.x && dec[c].mn.y <= exact.mn.y && dec[c].mn.z <= exact.mn.z &&
-                  dec[c].mx.x >= exact.mx.x && dec[c].mx.y >= exact.mx.y && dec[c].mx.z >= exact.mx.z)) {
-                bad++;
-                if (getenv("FW_WIDE_DEBUG")) fprintf(stderr, "node %u child %d ref %x: dec [%g %g %g | %g %g %g] exact [%g %g %g | %g %g %g]\n", rec.node, c, r[c], dec[c].mn.x, dec[c].mn.y, dec[c].mn.z,
-                                                      dec[c].mx.x, dec[c].mx.y, dec[c].mx.z, exact.mn.x, exact.mn.y, exact.mn.z, exact.mx.x, exact.mx.y, exact.mx.z);
-            }
+                  dec[c].mx.x >= exact.mx.x && dec[c].mx.y >= exact.mx.y && dec[c].mx.z >= exact.mx.z)) bad++;
             if (t.fmt == fw::WIDE_F32 && (r[c] & fw::W_LEAF) && std::memcmp(&dec[c], &item_boxes[r[c] & 0x7fffu], sizeof(Box)) != 0) bad++;   // an item's own box, bit for bit
-            if (r[c] & fw::W_LEAF) { const uint32_t it = r[c] & 0x7fffu; if (it >= seen.size() || seen[it]++) { bad++; if (getenv("FW_WIDE_DEBUG")) fprintf(stderr, "node %u child %d: item %u seen twice or out of range\n", rec.node, c, it); } leaves++; }
-            else { if (r[c] <= rec.node) { bad++; if (getenv("FW_WIDE_DEBUG")) fprintf(stderr, "node %u child %d: backward reference %u\n", rec.node, c, r[c]); } todo.push_back({r[c], Box{}, false}); }
+            if (r[c] & fw::W_LEAF) { const uint32_t it = r[c] & 0x7fffu; if (it >= seen.size() || seen[it]++) bad++; leaves++; }
+            else { if (r[c] <= rec.node) bad++; todo.push_back({r[c], Box{}, false}); }
         }
     }
     for (uint32_t s : seen) if (s != 1) bad++;

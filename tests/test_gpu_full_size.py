@@ -177,8 +177,14 @@ def test_bench_line_carries_roofline_parity_and_one_shot():
     d = _bench(["--width", "96", "--height", "96", "--spp", "32", "--steps", "2", "--warmup", "1", "--parity-seconds", "5"])
     assert d["unit"] == "Mrays/s" and d["scaling"] == "strong" and d["vs_baseline"] is None
     r = d["roofline"]
-    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["peak"] == 8000.0
-    assert r["other_kernel"]["kernel"] == "k_extend"
+    # `roofline` names the kernel class with the larger exclusive time; the other class rides along, and no bound is ever null
+    assert 0 < r["frac"] < 1 and r["peak"] == 8000.0
+    if r["kernel"] == "k_shade":
+        assert r["bound"] == "hbm" and r["other_kernel"]["kernel"] == "k_extend"
+        assert r["other_kernel"]["bound"] in ("latency", "valu_issue", "hbm")
+    else:
+        assert r["kernel"].startswith("k_extend") and r["bound"] in ("latency", "valu_issue", "hbm")
+        assert r["other_kernel"]["kernel"] == "k_shade" and r["other_kernel"]["bound"] == "hbm"
     assert d["parity"]["pass"] and d["parity"]["rays_equal"] and d["parity"]["u8_diffs"] == 0 and d["parity"]["timed_frame_equals_checked_frame"]
     o = d["one_shot"]
     assert o["ms_wall"] >= o["ms_scene"] + o["ms_render"] > 0
