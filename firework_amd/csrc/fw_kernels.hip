@@ -1507,6 +1507,9 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
 #ifndef FW_DEFER_WAVES
 #define FW_DEFER_WAVES 7
 #endif
+#ifndef FW_DEFER_LDS_PAD
+#define FW_DEFER_LDS_PAD 0      // timing builds: LDS a workgroup of the box-list scan asks for beyond its lists (caps its waves per CU)
+#endif
 #ifndef FW_SCAN_WAVES
 #define FW_SCAN_WAVES 6
 #endif
@@ -3448,7 +3451,7 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
 #if FW_AB
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 #endif
-    else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)2 * 64 * DEFER_FIELDS * 4, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
+    else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)2 * 64 * DEFER_FIELDS * 4 + FW_DEFER_LDS_PAD, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
 void launch_extend_exact(const LaunchCfg &c, const DScene &sc, const DFrame &f, const DPaths &in, float2 *hits, int segment, bool use_bvh) {
