@@ -1522,7 +1522,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // (pixel-major bits need the sample index of a path from a float quotient that is exact only while spp_batch < 2^21: dep_bit_of)
     fr.dep_pixel_major = (((n_pix <= 65536u && !O.dep_slot_major) || O.dep_pixel_major) && spp_b < (1u << 21)) ? 1u : 0u;
     fr.ex = sc->ex; fr.ex.mode = exact_mode;
-    fr.chain_bits = (O.no_chain || fused_req) ? 0u : sc->chain_bits;
+    fr.chain_bits = (O.no_chain || fused_req || cfg.shade_mode == 2) ? 0u : sc->chain_bits;      // k_bounce and k_shade's list mode (A/B build) carry the running product
     fr.skip_zero_deposits = (env.kind == 0 && env.color[0] == 0.f && env.color[1] == 0.f && env.color[2] == 0.f && !O.no_zero_skip) ? 1u : 0u;
 
     // per-launch timing (FW_FLAG_TIME_KERNELS): one event after every launch on the launch's own stream; the end of

@@ -339,11 +339,16 @@ def test_fused_bounce_kernel_is_bit_identical_to_the_split_kernels(monkeypatch):
         s, r = scenes.config(name, 48, 40, 12)
         r.use_bvh(bvh)
         monkeypatch.delenv("FIREWORK_FUSED", raising=False)
+        monkeypatch.setenv("FIREWORK_NO_CHAIN", "1")      # k_bounce carries the running product: compare with the split kernels doing the same
         split = r.render_full(s)
+        monkeypatch.delenv("FIREWORK_NO_CHAIN", raising=False)
+        chain = r.render_full(s)                          # the default (material-id chain where the scene allows it): the same u8 frame
         monkeypatch.setenv("FIREWORK_FUSED", "1")
         fused = r.render_full(s)
+        monkeypatch.delenv("FIREWORK_FUSED", raising=False)
         assert fused.stats["n_extend_launches"] == 0 and split.stats["n_extend_launches"] > 0
         assert np.array_equal(split.linear, fused.linear) and split.stats["rays"] == fused.stats["rays"]
+        assert np.array_equal(chain.rgb8, fused.rgb8) and chain.stats["rays_per_depth"] == fused.stats["rays_per_depth"]
 
 
 def test_deposit_bitmap_layouts_and_hit_record_sizes_are_bit_identical(monkeypatch):

@@ -1,4 +1,5 @@
 #!/bin/bash
+set -o pipefail
 # Round-4 evidence from the final kernel sources.   usage: tools/r04_final.sh <tag> <part>
 #   1: GPU tests (default build, then the -DFW_AB=1 build), the bench line, every config at full size, teapot, multi-rank rehearsals, first calls, shares
 #   2: full-sample-count parity of every config against the oracle (tools/full_parity.py) + the randomized sweep
@@ -18,6 +19,8 @@ case $PART in
   FIREWORK_TRACE=1 timeout -k 10 200 python3 tools/oneshot.py 4 > $O/oneshot.log 2>&1; grep -v "^\[" $O/oneshot.log | tail -12
   timeout -k 10 200 python3 tools/share.py 2>/dev/null | tee $O/share.txt
   cat $O/summary.txt ;;
+1b)
+  FIREWORK_LIB=$V/lib_ab.so timeout -k 10 600 python3 -m pytest tests -m gpu -q 2>&1 | tee $O/tests_ab_build.log | tail -3; echo "tests (FW_AB build) rc=$?" | tee -a $O/summary.txt ;;
 2)
   rm -f $O/full_parity.jsonl
   timeout -k 10 1100 python3 tools/full_parity.py --out $O/full_parity.jsonl | cut -c1-260; echo "full parity rc=$?" | tee -a $O/summary.txt
