@@ -6,6 +6,7 @@ seed, measured on the post-gamma, clamped, pre-quantisation floats
 is compiled with -ffp-contract=off and IEEE division/sqrt, hit/miss decisions are bit-identical and the
 observed RMS is far below the gate; the linear-image check below is much tighter than 1e-3.
 """
+import os
 import numpy as np
 import pytest
 
@@ -315,6 +316,8 @@ def test_chain_state_equals_the_running_product_in_u8_and_the_oracle_before_gamm
     of state instead of 16) and multiplies them out when it deposits, back to front — the association of the reference's recursion
     (render.rs:23-28).  Against the 16-byte running product (NO_CHAIN): same rays, same u8.  Against the oracle: the pre-gamma means
     BIT for bit (the running product is one rounding per path away from them)."""
+    if os.environ.get("FIREWORK_FUSED") or os.environ.get("FIREWORK_SHADE_LIST"):
+        pytest.skip("k_bounce and k_shade's list mode (A/B build) carry the running product: there is no chain state to compare under this switch")
     cases = [scenes.config("C2_cornell_box", 96, 96, 40), scenes.config("C3_suzanne", 160, 90, 16), scenes.config("C4b_volume_test", 96, 96, 24)]
     sh, rh = scenes.hdri_test(scenes.synthetic_hdr(512, 256))
     cases.append((sh, rh.width(96).height(96).samples(16)))
@@ -342,13 +345,11 @@ def test_fused_bounce_kernel_is_bit_identical_to_the_split_kernels(monkeypatch):
         monkeypatch.setenv("FIREWORK_NO_CHAIN", "1")      # k_bounce carries the running product: compare with the split kernels doing the same
         split = r.render_full(s)
         monkeypatch.delenv("FIREWORK_NO_CHAIN", raising=False)
-        chain = r.render_full(s)                          # the default (material-id chain where the scene allows it): the same u8 frame
         monkeypatch.setenv("FIREWORK_FUSED", "1")
         fused = r.render_full(s)
         monkeypatch.delenv("FIREWORK_FUSED", raising=False)
         assert fused.stats["n_extend_launches"] == 0 and split.stats["n_extend_launches"] > 0
-        assert np.array_equal(split.linear, fused.linear) and split.stats["rays"] == fused.stats["rays"]
-        assert np.array_equal(chain.rgb8, fused.rgb8) and chain.stats["rays_per_depth"] == fused.stats["rays_per_depth"]
+        assert np.array_equal(split.linear, fused.linear) and split.stats["rays_per_depth"] == fused.stats["rays_per_depth"]
 
 
 def test_deposit_bitmap_layouts_and_hit_record_sizes_are_bit_identical(monkeypatch):
