@@ -357,26 +357,48 @@ def roofline_objects(acc, args, tr, renderer, steps=None):
     single_extend_kernel = False
     other_bound = other_src = None
     workload = f"{args.config} {renderer.settings['width']}x{renderer.settings['height']} @{renderer.settings['samples']}spp"
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+    # a counter summary of this build: of this very workload, else of the same scene and size at another sample count (a launch is one
+    # segment of one BATCH, and batches have the same size whatever the frame's sample count: part2 is profiled at 256 of its 4096 spp)
+    def same_launches(d):
+        w = d.get("workload") or ""
+        if w == workload:
+            return 2
+        return 1 if w.split(" @")[0] == workload.split(" @")[0] and w.split(" @")[0] else 0
+
+    def candidates(pattern):
+        found = []
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
+            try:
+                d = json.load(open(path))
+            except Exception:
+                continue
+            if d.get("source_sha") == sha and same_launches(d):
+                found.append((same_launches(d), path, d))
+        return [(path, d) for _, path, d in sorted(found, key=lambda x: -x[0])]
+
+    for path, d in candidates("*_pmc.json"):
         try:
-            d = json.load(open(path))
-            if d.get("source_sha") != sha or d.get("workload") != workload or tr.world != 1:
+            if tr.world != 1:
                 continue                                  # the profiles are whole-frame runs: a rank's share moves 1/N of those bytes per launch
             k = [k for k in d["kernels"] if "k_shade" in k][0]
-            traffic, traffic_src = d["kernels"][k]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+            traffic, traffic_src = d["kernels"][k]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT) + ("" if d.get("workload") == workload else f" (taken at {d.get('workload')}: same batch per launch)")
             ke = max((k for k in d["kernels"] if "k_extend" in k or "k_blas" in k), key=lambda k: d["kernels"][k]["us_total_in_these_passes"])
             other_traffic = d["kernels"][ke]["hbm_bytes_per_launch"]
             single_extend_kernel = sum(1 for k in d["kernels"] if "k_extend" in k or "k_blas" in k) == 1
             break
         except Exception:
             continue
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq.json")), reverse=True):
+    shade_bound = None
+    for path, d in candidates("*_sq.json"):
         try:
-            d = json.load(open(path))
-            if d.get("source_sha") != sha or d.get("workload") != workload:
-                continue
             k = max((k for k in d["kernels"] if "k_extend" in k or "k_blas" in k), key=lambda k: d["kernels"][k]["us_total"])   # the longest of the extend-class kernels
-            other_bound, other_src = d["kernels"][k]["bound"], os.path.relpath(path, ROOT)
+            other_bound = d["kernels"][k]["bound"]
+            other_src = os.path.relpath(path, ROOT) + f": {k}" + ("" if d.get("workload") == workload else f" (taken at {d.get('workload')})")
+            ks = [k for k in d["kernels"] if "k_shade" in k]
+            if ks:
+                e = d["kernels"][ks[0]]
+                shade_bound = {"counters": e["bound"], "valu_issue_util": e.get("valu_issue_util"), "hbm_util_of_streaming": e.get("hbm_util_of_streaming"),
+                               "lane_utilisation": e.get("lane_utilisation"), "source": os.path.relpath(path, ROOT)}
             break
         except Exception:
             continue
@@ -388,6 +410,7 @@ def roofline_objects(acc, args, tr, renderer, steps=None):
         "traffic": traffic, "traffic_source": traffic_src, "frac_traffic": frac_traffic,
         "algorithmic_bytes_per_launch": shd_bytes / n_sh, "avg_launch_us": shd_s * 1e6 / n_sh,
         "bytes_per_ray": shd_bytes / max(1.0, float(exact["rays"])),
+        "counters": shade_bound,      # what the SQ counters of this build say k_shade waits for (round 4: with the 8-byte state its instruction issue is as busy as its HBM streams)
         "bytes": "this layout's streams, exact from the queue counters; zero deposits elided over a black environment are not counted "
                  f"({exact['deposits']} of {exact['samples']} radiance records written)",
         "other_kernel": {"kernel": "k_extend", "bound": other_bound, "bound_source": other_src,
@@ -402,8 +425,8 @@ def roofline_objects(acc, args, tr, renderer, steps=None):
     # time are quoted against the HBM peak all the same (that is what the fraction means), next to the bound the counter summary names.
     ok = res["roofline"]["other_kernel"]
     if ok["bound"] is None:
-        ok["bound"] = "latency" if renderer.settings["use_bvh"] else "valu_issue"
-        ok["bound_source"] = "default by kernel class (DESIGN.md section 5: tree walks wait for dependent node fetches, the linear scan for vector issue); no counter summary of this build and workload under profiles/"
+        ok["bound"] = "valu_issue"
+        ok["bound_source"] = "default by kernel class (profiles/r04z_*_sq.json: the wide-node walks and the scans issue vector instructions in 0.86-0.99 of their SIMD cycles); no counter summary of this build and workload under profiles/"
     if ext_s > shd_s:
         sh = {k: v for k, v in res["roofline"].items() if k != "other_kernel"}
         res["roofline"] = {"bound": ok["bound"], "kernel": "k_extend (scan + walks of one segment)", "achieved": ok["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
