@@ -369,7 +369,8 @@ def test_deposit_bitmap_layouts_and_hit_record_sizes_are_bit_identical(monkeypat
         for f in frames[1:]:
             assert np.array_equal(f.linear, frames[0].linear) and f.stats["deposits"] == frames[0].stats["deposits"]
             assert f.stats["rays_per_depth"] == frames[0].stats["rays_per_depth"]
-        assert frames[3].stats["bytes_shade"] > frames[0].stats["bytes_shade"]      # 8-byte hit records
+        if not os.environ.get("FIREWORK_FUSED"):                                    # (k_bounce, A/B build: no hit records at all)
+            assert frames[3].stats["bytes_shade"] > frames[0].stats["bytes_shade"]  # 8-byte hit records
 
 
 def test_deferred_boxes_of_the_linear_scan_are_bit_identical(oracle, monkeypatch):
