@@ -332,8 +332,9 @@ def one_shot_cold(args):
         cp = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, FIREWORK_TRACE="1"))
         d = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
         d["trace"] = [l for l in cp.stderr.splitlines() if l.startswith("[firework]")][:12]     # where the first call's host time went (FIREWORK_TRACE)
-        d["region"] = ("first fw_render_scene call of a fresh process: wall = path arena + scene + render + D2H; the library's load (ms_library_load: HIP context, "
-                       "code objects, staging — its static initialiser) comes before it, like the loading of the reference's binary; then the first calls of two "
+        d["region"] = ("first fw_render_scene call of a fresh process: wall = scene + render + D2H; the library's load (ms_library_load: HIP context, "
+                       "code objects, staging and the path arena — its static initialiser; the arena's hipMalloc takes 0.4 ms to 1.4 s by the state of the "
+                       "device's memory) comes before it, like the loading of the reference's binary; then the first calls of two "
                        "other configs in the same process (the arena may have to grow)")
         return d
     except Exception as e:

@@ -671,6 +671,17 @@ void warm_device(int dev) {
     if (!ws->ev_upload && hipEventCreateWithFlags(&ws->ev_upload, hipEventDisableTiming) != hipSuccess) ws->ev_upload = nullptr;
     for (int l = 0; l < 2; l++) if (!ws->lanes[l].stream && hipStreamCreateWithFlags(&ws->lanes[l].stream, hipStreamNonBlocking) != hipSuccess) ws->lanes[l].stream = nullptr;
     if (!ws->staging || !ws->upload_stream) return;
+    // The path arena too (render_impl carves every lane buffer out of it).  Its hipMalloc is lazy on a device whose memory is clean (0.4 ms
+    // for 64 GiB) and is NOT where the driver has to clear the pages first: 187 ms and 1 448 ms were measured for the same call on two
+    // other boxes of the pool (gpurun_out/r04z/bench.json, `one_shot_cold.trace`) — inside a first frame that renders in 38 ms.  Pools are
+    // no part of any frame: they are made here, with the context and the code objects.
+    {
+        size_t free_b = 0, total_b = 0;
+        if (!ws->arena.p && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t want = std::min<size_t>((size_t)64 << 30, free_b / 3) & ~(((size_t)1 << 30) - 1);
+            if (want >= ((size_t)1 << 30) && ws->arena.alloc(want) != FW_OK) { (void)hipGetLastError(); g_last_error.clear(); }
+        }
+    }
     void *tmp = nullptr;
     if (hipMalloc(&tmp, 256) != hipSuccess) return;
     std::memset(ws->staging, 0, 256);
