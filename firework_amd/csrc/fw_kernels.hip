@@ -993,15 +993,15 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
 }
 
 // objects/volume.rs:56-82
-template <int EXACT = 0>
+template <int EXACT = 0, bool MESH = true>
 __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const Ray &r, float tmin, float tmax,
                                            uint32_t *stack_base, const RngKey &key, uint32_t segment, uint32_t obj_index, float &t_out) {
     const float FMAX = 3.40282347e+38f;
     uint32_t ik = obj_inner(o), prim;
     float t1, t2;
     const uint32_t root = EXACT ? sc.obj_ref_blas[obj_index] : o.aux0;
-    if (!hit_shape<EXACT>(sc, ik, o.q3, o.q4, root, o.aux1, r, -FMAX, FMAX, stack_base, t1, prim)) return false;
-    if (!hit_shape<EXACT>(sc, ik, o.q3, o.q4, root, o.aux1, r, t1 + 0.0001f, FMAX, stack_base, t2, prim)) return false;
+    if (!hit_shape<EXACT, MESH>(sc, ik, o.q3, o.q4, root, o.aux1, r, -FMAX, FMAX, stack_base, t1, prim)) return false;
+    if (!hit_shape<EXACT, MESH>(sc, ik, o.q3, o.q4, root, o.aux1, r, t1 + 0.0001f, FMAX, stack_base, t2, prim)) return false;
     t1 = fmaxf(t1, tmin);
     t2 = fminf(t2, tmax);
     if (t1 >= t2) return false;
@@ -1022,7 +1022,7 @@ __device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint3
                                            float tmax, uint32_t *stack_base, const RngKey &key, uint32_t segment, float &t, uint32_t &prim) {
     Ray r = to_object_space(o, world);
     uint32_t kind = obj_kind(o);
-    if (MEDIUM && kind == 6) { prim = 0; return hit_medium<EXACT>(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
+    if (MEDIUM && kind == 6) { prim = 0; return hit_medium<EXACT, MESH>(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
     const uint32_t root = (EXACT && kind == 5u) ? sc.obj_ref_blas[obj_index] : o.aux0;
     return hit_shape<EXACT, MESH>(sc, kind, o.q3, o.q4, root, o.aux1, r, tmin, tmax, stack_base, t, prim);
 }
@@ -1173,7 +1173,11 @@ __device__ __forceinline__ void hoisted_hits(const DScene &sc, const Ray &r, V3 
 
 // Closest hit of one ray: the linear scan of scene.rs:137-149 or the TLAS walk of bvh.rs:115-151.  With DEFER a
 // ray that reaches a mesh leaf of the TLAS reports (deferred, deferred_obj) instead of entering the BLAS.
-template <bool USE_BVH, bool DEFER>
+// MESH = false: the caller's scene holds no mesh (launch_extend checks): the mesh walk is compiled out of the linear scan, which is
+// bound by instruction issue and whose code then fits the instruction cache (k_extend_linear: 93 KB with it)
+// MEDIUM = false likewise for a scene without a ConstantMedium (its two boundary tests and double-precision log10): hdri's scan is then
+// a quarter of the code and keeps its registers
+template <bool USE_BVH, bool DEFER, bool MESH = true, bool MEDIUM = true>
 __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, const RngKey &key, int segment,
                                             uint32_t *my_stack, uint32_t *blas_stack, float &best_t, uint32_t &best_obj,
                                             uint32_t &best_prim, bool &deferred, uint32_t &deferred_obj, bool soft = false) {
@@ -1208,7 +1212,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
                     if (__ballot(maybe) == 0ull) continue;
                 }
                 float t; uint32_t prim;
-                if (hit_object(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+                if (hit_object<MEDIUM, 0, MESH>(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
             }
         } else {
             // the loop of all later segments: no pre-test, nothing but the scan (the scalar unit is as busy as the VALUs here)
@@ -1216,7 +1220,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
             for (uint32_t k = 0; k < sc.n_objects; k++, op += OBJ_Q) {
                 Obj o = load_obj(op, 0);
                 float t; uint32_t prim;
-                if (hit_object(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+                if (hit_object<MEDIUM, 0, MESH>(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
             }
         }
     } else {
@@ -1261,7 +1265,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
     }
 }
 
-template <bool USE_BVH, bool REFILL, bool PARK>
+template <bool USE_BVH, bool REFILL, bool PARK, bool MESH = true, bool MEDIUM = true>
 __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, const DPaths &in, float2 *__restrict__ hits,
                                             const DQueue &q, int segment, int tlas_levels, int stack_levels, const DPark &park) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
@@ -1478,7 +1482,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
             RngKey key{0, 0, 0};
             if (sc.has_medium) key = key_of(f, __float_as_uint(load_home(in, i, f, segment)));
             if (!skip_ray(f.ex, r))     // a NaN ray's record comes from k_extend_exact
-                closest_hit<USE_BVH, USE_BVH>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj,
+                closest_hit<USE_BVH, USE_BVH, MESH, MEDIUM>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj,
                                               USE_BVH && sc.has_mesh && soft_ray(f.ex, r.d, sc.soft_shear));
             if (!USE_BVH && f.hit4) reinterpret_cast<uint32_t *>(hits)[i] = __float_as_uint(pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y);   // the code alone: k_shade recomputes t
             else if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
@@ -1513,8 +1517,13 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
 #ifndef FW_SCAN_WAVES
 #define FW_SCAN_WAVES 6
 #endif
-template <bool PARK>
-__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVES, 8))) void k_extend_scan(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment,
+#ifndef FW_SCAN_WAVES_PLAIN
+#define FW_SCAN_WAVES_PLAIN 7      // the plain scan (no medium, meshes parked) fits 72 registers without spills: suzanne 64.9 -> 64.2 ms, teapot @128 48.6 -> 47.2 (gpurun_out/r04y/scan_variants.txt)
+#endif
+// PLAIN: the scene holds no ConstantMedium (the host checks) — meshes are parked, never walked here, so without a medium neither the mesh
+// walk nor the medium's code is needed: compiled out (53 KB of code and 11 spilled registers with them)
+template <bool PARK, bool PLAIN = false>
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(PLAIN ? FW_SCAN_WAVES_PLAIN : FW_SCAN_WAVES, 8))) void k_extend_scan(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment,
                                                     int tlas_levels, float4 *__restrict__ park_a, float2 *__restrict__ park_b, float4 *__restrict__ park_m,
                                                     uint32_t *__restrict__ park_count, uint32_t park_stride) {
     // the park arrays are `__restrict__` kernel arguments, not a DPark: only then can the compiler prove that the stores
@@ -1558,7 +1567,7 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_SCAN_WAVE
                     continue;                                                                            // parked, the others were walked here, in place, from L2)
                 }
                 float t; uint32_t prim;
-                if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+                if (PLAIN ? hit_object<false, 0, false>(sc, o, k, r, TMIN, TMAX, nullptr, key, segment, t, prim) : hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
                     if ((!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, k, r.o, inv)) { have = true; best_t = t; best_obj = k; best_prim = prim; }
                 }
             }
@@ -1730,6 +1739,16 @@ void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ 
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(7, 8)))
 void k_extend_linear(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
     extend_body<false, false, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
+}
+// the same for a scene without meshes (hdri, volume): the mesh walk compiled out
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(7, 8)))
+void k_extend_linear_nomesh(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
+    extend_body<false, false, false, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
+}
+// ... and without media either (hdri)
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(7, 8)))
+void k_extend_linear_plain(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
+    extend_body<false, false, false, false, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
 }
 #if FW_AB
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(5, 8)))
@@ -2318,6 +2337,7 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
 }
 
 // k_extend_tlas_lds over WIDE_F32 nodes (scenes without meshes: part2's TLAS, random_spheres)
+template <bool MEDIUM>      // false: the scene holds no ConstantMedium (random_spheres): its code — two boundary tests and a double-precision log10 — compiled out
 __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q,
                                                                           int segment, uint32_t n_nodes, uint32_t levels) {
     extern __shared__ uint32_t lds_w[];
@@ -2413,7 +2433,8 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene
             RngKey key{0, 0, 0};
             if (sc.has_medium) key = key_of(f, path_id);
             float t; uint32_t prim;
-            if (hit_object(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)) {
+            // (with a medium the generic test stays: compiling the mesh walk out of the medium's boundary tests alone made part2 1 % slower, 82.6 -> 83.4 ms)
+            if (hit_object<MEDIUM, 0, MEDIUM>(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)) {
                 if ((!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, item, wo, inv)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
             }
         }
@@ -3383,7 +3404,8 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     auto walk_grid = [&](uint32_t waves) { return std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + waves - 1) / waves); };
     if (use_bvh && c.tlas_refill && c.has_mesh) {
         // TLAS walk that parks mesh rays in HBM, then their BLAS walks; a medium around a mesh still walks it in place (blas levels)
-        if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<true>, eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park.ray_a, park.ray_b, park.meta, park.pcount, park.stride);
+        if (sc.n_objects <= TLAS_SCAN_MAX && !sc.has_medium) hipLaunchKernelGGL((k_extend_scan<true, true>), eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park.ray_a, park.ray_b, park.meta, park.pcount, park.stride);
+        else if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<true>, eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park.ray_a, park.ray_b, park.meta, park.pcount, park.stride);
         else hipLaunchKernelGGL(k_extend_tlas_park, sg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
         // The parked rays' BLAS walks.  WIDE nodes out of LDS where the scene has them (f32, or quantised for a BLAS too big for those):
         // as many waves per workgroup (16, 12, 8) as fit next to the tree, the triangles too when 16 waves still fit with them.
@@ -3433,9 +3455,13 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
             uint32_t waves = 0;
             for (uint32_t w : {16u, 12u, 8u}) if (lds_walk_bytes(tree, w, wl, c.q.n_waves, walk_grid(w)) <= LDS_TREE_LIMIT) { waves = w; break; }
             if (waves) {
-                if (lds_attr_needed(3)) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                if (lds_attr_needed(3)) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                }
                 const dim3 lg(walk_grid(waves));
-                hipLaunchKernelGGL(k_extend_tlas_wide, lg, dim3(waves * 64), lds_walk_bytes(tree, waves, wl, c.q.n_waves, lg.x), c.stream, sc, f, in, hits, c.q, segment, c.wtlas_nodes, wl);
+                if (sc.has_medium) hipLaunchKernelGGL(k_extend_tlas_wide<true>, lg, dim3(waves * 64), lds_walk_bytes(tree, waves, wl, c.q.n_waves, lg.x), c.stream, sc, f, in, hits, c.q, segment, c.wtlas_nodes, wl);
+                else hipLaunchKernelGGL(k_extend_tlas_wide<false>, lg, dim3(waves * 64), lds_walk_bytes(tree, waves, wl, c.q.n_waves, lg.x), c.stream, sc, f, in, hits, c.q, segment, c.wtlas_nodes, wl);
                 return;
             }
         }
@@ -3452,6 +3478,8 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 #endif
     else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)2 * 64 * DEFER_FIELDS * 4 + FW_DEFER_LDS_PAD, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
+    else if (!c.has_mesh && !sc.has_medium) hipLaunchKernelGGL(k_extend_linear_plain, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+    else if (!c.has_mesh) hipLaunchKernelGGL(k_extend_linear_nomesh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 }
 void launch_extend_exact(const LaunchCfg &c, const DScene &sc, const DFrame &f, const DPaths &in, float2 *hits, int segment, bool use_bvh) {
@@ -3505,10 +3533,10 @@ void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
 void preload_kernels() {
     hipFuncAttributes a;
 #define FW_TOUCH(k) (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k))
-    FW_TOUCH(k_raygen); FW_TOUCH(k_extend_linear); FW_TOUCH(k_extend_linear_defer); FW_TOUCH(k_extend_scan<true>); FW_TOUCH(k_extend_scan<false>);
+    FW_TOUCH(k_raygen); FW_TOUCH(k_extend_linear); FW_TOUCH(k_extend_linear_nomesh); FW_TOUCH(k_extend_linear_plain); FW_TOUCH(k_extend_linear_defer); FW_TOUCH(k_extend_scan<true>); FW_TOUCH((k_extend_scan<true, true>)); FW_TOUCH(k_extend_scan<false>);
     FW_TOUCH(k_extend_tlas); FW_TOUCH(k_extend_tlas_park); FW_TOUCH(k_blas); FW_TOUCH(k_blas_lds<true>); FW_TOUCH(k_blas_lds<false>); FW_TOUCH(k_extend_tlas_lds);
     FW_TOUCH((k_blas_wide<WIDE_F32, true>)); FW_TOUCH((k_blas_wide<WIDE_F32, false>)); FW_TOUCH((k_blas_wide<WIDE_Q8, true>)); FW_TOUCH((k_blas_wide<WIDE_Q8, false>));
-    FW_TOUCH(k_extend_tlas_wide); FW_TOUCH(k_extend_exact); FW_TOUCH(k_queue_totals); FW_TOUCH(k_count_deposits); FW_TOUCH(k_accumulate); FW_TOUCH(k_tile_order);
+    FW_TOUCH(k_extend_tlas_wide<true>); FW_TOUCH(k_extend_tlas_wide<false>); FW_TOUCH(k_extend_exact); FW_TOUCH(k_queue_totals); FW_TOUCH(k_count_deposits); FW_TOUCH(k_accumulate); FW_TOUCH(k_tile_order);
     FW_TOUCH(k_resolve); FW_TOUCH(k_scatter_tiles);
     FW_TOUCH((k_shade<0, 0, false>)); FW_TOUCH((k_shade<0, 0, true>)); FW_TOUCH((k_shade<0, 1, false>)); FW_TOUCH((k_shade<0, 1, true>));
     FW_TOUCH((k_shade<1, 0, false>)); FW_TOUCH((k_shade<1, 0, true>)); FW_TOUCH((k_shade<1, 1, false>)); FW_TOUCH((k_shade<1, 1, true>));
