@@ -2882,7 +2882,8 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
         bool need_uv = (mbits & MF_NEEDS_UV) != 0, tex_const = (mbits & MF_TEX_CONST) != 0;
         HitInfo h = rebuild_hit(sc, o, r, t_hit, hit_code & ((1u << sc.prim_bits) - 1u), need_uv, f.hit4 != 0u);
         V3 texc = mk(m1.x, m1.y, m1.z);                                      // inline ConstantTexture / Metal albedo
-        if (!CHEAP_ONLY && !tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
+        // (the chain state exists only where every such texture is a constant — the host checks —, so its kernels carry no texture code)
+        if (!CHEAP_ONLY && !CHAIN && !tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
         if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
             rad = carried(texc);
         } else if (segment < 10) {                                             // render.rs:21
@@ -2965,7 +2966,7 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
     const float4 *objp = sc.obj, *matp = sc.mat, *texp = sc.tex;
     __shared__ uint16_t shade_list[128];                                 // MODE 2: queue positions of the expensive paths not yet shaded (< 64 + 64)
-    if (sc.has_perlin && MODE != 1) { stage_perm(); if (!LDS_TAB) __syncthreads(); }
+    if (sc.has_perlin && MODE != 1 && !CHAIN) { stage_perm(); if (!LDS_TAB) __syncthreads(); }
     if (LDS_TAB) {
         const uint32_t no = LDS_TAB == 1 ? sc.n_objects * OBJ_Q : 0u, nm = 2 * n_mat, nt = 2 * n_tex;
         if (LDS_TAB == 1) for (uint32_t k = threadIdx.x; k < no; k += WB) lds_tables[k] = sc.obj[k];
