@@ -518,6 +518,18 @@ __device__ __forceinline__ bool hit_rect(float a_min, float a_max, float b_min, 
     const float ma = __builtin_amdgcn_fmed3f(pa, a_min, a_max), mb = __builtin_amdgcn_fmed3f(pb, b_min, b_max);
     return !(t < tmin || t > tmax) && !(pa < ma || pa > ma) && !(pb < mb || pb > mb);
 }
+// The non-degenerate form above with the reciprocal of the plane axis' direction component handed in: the walls of a room share three of
+// them (k_extend_linear_defer).  rc == make_rcp(comp(r.d, OT)), so fdiv gives the bits of the form above.
+template <int AX>
+__device__ __forceinline__ bool hit_rect_rcp(float a_min, float a_max, float b_min, float b_max, float k, const Ray &r, const Rcp &rc,
+                                             float tmin, float tmax, float &t_out) {
+    constexpr int A1 = (AX == 2) ? 1 : 0, A2 = (AX == 0) ? 1 : 2, OT = (AX == 0) ? 2 : (AX == 1 ? 1 : 0);
+    const float t = fdiv(k - comp(r.o, OT), rc);
+    const float pa = comp(r.o, A1) + t * comp(r.d, A1), pb = comp(r.o, A2) + t * comp(r.d, A2);
+    t_out = t;
+    const float ma = __builtin_amdgcn_fmed3f(pa, a_min, a_max), mb = __builtin_amdgcn_fmed3f(pb, b_min, b_max);
+    return !(t < tmin || t > tmax) && !(pa < ma || pa > ma) && !(pb < mb || pb > mb);
+}
 template <bool DEGENERATE>
 __device__ __forceinline__ bool hit_rect_kind_t(uint32_t kind, float4 q3, float k, const Ray &r, float tmin, float tmax, float &t) {
     if (kind == 1) return hit_rect<0, DEGENERATE>(q3.x, q3.y, q3.z, q3.w, k, r, tmin, tmax, t);
@@ -1692,10 +1704,24 @@ void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ 
         const Ray r = make_ray(ra, rb, f, segment);
         if (active) {
             const float4 *op = sc.obj;
+            // A room's walls are PLAIN rectangles (no rotation, no degenerate interval), two or three per axis: they share the reciprocal of
+            // their axis' direction component — v_rcp_f32 is a quarter-rate instruction, and the generic test computed it once per rectangle —
+            // and skip the generic dispatch.  Wave-uniform branch (the record came through scalar loads); the quotients are hit_rect's, bit for
+            // bit.  k_extend 16.2 -> 14.25 ms, cornell 36.0 -> 33.2 ms (gpurun_out/r04y/cornell_rcp.txt).  (The same in the generic linear scans
+            // costs them registers they do not have — hdri 7.3 -> 7.8 ms, volume 13.8 -> 15.1 —, and spelled out inside hit_rect3d, where the
+            // compiler already shares them, it lost as well: r04y/shared_rcp.txt.)
+            const Rcp rcx = make_rcp(r.d.x), rcy = make_rcp(r.d.y), rcz = make_rcp(r.d.z);
             for (uint32_t k = 0; k < n_first; k++, op += OBJ_Q) {
                 const Obj o = load_obj(op, 0);
-                float t; uint32_t prim;
-                if (hit_object<false, 0, false>(sc, o, k, r, TMIN, best_t, nullptr, nokey, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+                float t; uint32_t prim = 0; bool h;
+                const uint32_t kind = obj_kind(o);
+                if (kind >= 1u && kind <= 3u && !(obj_flags(o) & OF_ROTATED) && o.q4.y == 0.f) {
+                    const Ray ro{r.o - mk(o.q0.w, o.q1.w, o.q2.w), r.d};                                 // to_object_space without a rotation
+                    if (kind == 1u) h = hit_rect_rcp<0>(o.q3.x, o.q3.y, o.q3.z, o.q3.w, o.q4.x, ro, rcz, TMIN, best_t, t);
+                    else if (kind == 2u) h = hit_rect_rcp<1>(o.q3.x, o.q3.y, o.q3.z, o.q3.w, o.q4.x, ro, rcy, TMIN, best_t, t);
+                    else h = hit_rect_rcp<2>(o.q3.x, o.q3.y, o.q3.z, o.q3.w, o.q4.x, ro, rcx, TMIN, best_t, t);
+                } else h = hit_object<false, 0, false>(sc, o, k, r, TMIN, best_t, nullptr, nokey, segment, t, prim);
+                if (h) { best_t = t; best_obj = k; best_prim = prim; }
             }
             // conservative pre-tests (see closest_hit's segment-0 cull: approximate reciprocals, boxes inflated by 1e-4 of the
             // scene and ray-origin scale, NaN-dropping min/max), here per lane and also culled against the hit so far
