@@ -102,6 +102,51 @@ __device__ __forceinline__ V3 normalized(V3 a) { return a / mag(a); }
 struct Ray { V3 o, d; };
 __device__ __forceinline__ V3 ray_point(const Ray &r, float t) { return r.o + t * r.d; }
 
+// Phase statistics (debug builds only: tools/build_variant.sh phase -DFW_PHASE_STATS; tools/phase_stats.py): for up to PH_N code
+// sections of a kernel the cycles the WAVE spent in them (clock64 deltas, each active lane adding delta / active lanes), the
+// LANE-cycles (every active lane adding delta: lane-cycles / (64 x wave cycles) is the section's lane utilisation) and how often
+// the wave entered them.  Where the walks and k_shade lose their lanes, section by section (round 5).
+#ifdef FW_PHASE_STATS
+constexpr int PH_N = 20;
+__device__ unsigned long long g_phase[2 * 3 * PH_N];     // [kernel class: 0 the wide walks, 1 k_shade][section][lane-cycles, wave cycles, entries]
+struct Phase {
+    float lane[PH_N], wave[PH_N], cnt[PH_N];
+    __device__ __forceinline__ void init() { for (int k = 0; k < PH_N; k++) { lane[k] = 0.f; wave[k] = 0.f; cnt[k] = 0.f; } }
+    __device__ __forceinline__ void add(int k, long long t0) {      // called by the section's active lanes, at its end
+        const float d = (float)(clock64() - t0), pc = (float)__popcll(__ballot(1));
+        lane[k] += d; wave[k] += d / pc; cnt[k] += 1.f / pc;
+    }
+    __device__ __forceinline__ void count(int k) { const float pc = (float)__popcll(__ballot(1)); lane[k] += 1.f; cnt[k] += 1.f / pc; }   // lanes / entries only
+    __device__ __forceinline__ void flush(int cls) {
+        unsigned long long *g_phase_ = g_phase + cls * 3 * PH_N;
+        for (int k = 0; k < PH_N; k++) {
+            float a = lane[k], b = wave[k], c = cnt[k];
+            for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); c += __shfl_xor(c, o); }
+            if ((threadIdx.x & 63u) == 0) {
+                if (a > 0.f) atomicAdd(&g_phase_[3 * k], (unsigned long long)(a + 0.5f));
+                if (b > 0.f) atomicAdd(&g_phase_[3 * k + 1], (unsigned long long)(b + 0.5f));
+                if (c > 0.f) atomicAdd(&g_phase_[3 * k + 2], (unsigned long long)(c + 0.5f));
+            }
+        }
+    }
+};
+#define PH_DECL Phase ph_; ph_.init(); const long long ph_k0_ = clock64()      // the kernel's own span goes to section PH_N - 2
+#define PH_T0 const long long ph_t0_ = clock64()
+#define PH_ADD(k) ph_.add((k), ph_t0_)
+#define PH_COUNT(k) ph_.count(k)
+#define PH_FLUSH(cls) do { ph_.add(PH_N - 2, ph_k0_); ph_.flush(cls); } while (0)
+#define PH_ARG , Phase &ph_
+#define PH_PASS , ph_
+#else
+#define PH_DECL do { } while (0)
+#define PH_T0 do { } while (0)
+#define PH_ADD(k) do { } while (0)
+#define PH_COUNT(k) do { } while (0)
+#define PH_FLUSH(cls) do { } while (0)
+#define PH_ARG
+#define PH_PASS
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // counter RNG: pcg4d(pixel, sample, dimension, seed32) -> 4 x u32; float = (u >> 8) * 2^-24
 // ------------------------------------------------------------------------------------------------
@@ -128,9 +173,10 @@ __device__ __forceinline__ uint4 draw(const RngKey &k, uint32_t purpose, uint32_
 constexpr uint32_t MAX_REJECT = FW_MAX_REJECT;   // exit condition for the rejection loops (P(miss 1024x) ~ 1e-330)
 
 // util.rs:36-43
-__device__ __forceinline__ V3 random_in_unit_sphere(const RngKey &k, uint32_t segment) {
+__device__ __forceinline__ V3 random_in_unit_sphere(const RngKey &k, uint32_t segment PH_ARG) {
     V3 p = mk(0.f, 0.f, 0.f);
     for (uint32_t attempt = 0; attempt < MAX_REJECT; attempt++) {
+        PH_COUNT(19);
         uint4 u = draw(k, P_SCATTER, segment, attempt);
         p = 2.0f * mk(u2f(u.x), u2f(u.y), u2f(u.z)) - mk(1.f, 1.f, 1.f);
         if (mag_sq(p) < 1.0f) break;
@@ -2271,6 +2317,7 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
     WideSel sel = wide_sel<FMT>(inv);
     TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
     LdsStackW st{stacks + (size_t)wib * levels * 64u + lane, 0};
+    PH_DECL;
     uint32_t more = 0, pidx = 0;            // the meshes this ray still has to walk after the current one (park_next_mesh), and where its parked entry lies
     auto start_walk = [&](uint32_t mesh_obj, float4 ra, float2 rb) {
         obj = mesh_obj;
@@ -2296,9 +2343,11 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
                 const float2 rb = make_float2(bp(cb.x), bp(cb.y));
                 const float4 me = make_float4(bp(cm.x), bp(cm.y), bp(cm.z), bp(cm.w));
                 if (!act && rank < take) {
+                    PH_T0;
                     slot = __float_as_uint(me.x); more = __float_as_uint(me.y); bt = me.z; bcode = __float_as_uint(me.w);
                     pidx = c_bb + c_pos + rank;
                     start_walk(park_next_mesh(more), ra, rb);
+                    PH_ADD(0);
                 }
                 c_pos += take;
                 if (c_pos == c_n) {
@@ -2309,15 +2358,16 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
         } else if (n_idle == 64u) break;
 
         const uint32_t n_act = (uint32_t)__popcll(__ballot(act));
+        if (act) PH_COUNT(7);                                          // busy lanes per round
         for (;;) {
             // a triangle put aside while its lane walks on (k_blas_lds: one at most; same tests, same winner)
             if (act && (cur & W_LEAF) && cur != W_DONE && pend == W_DONE && st.sp > 0) { pend = cur; cur = st.pop(); }
             const bool walking = act && !(cur & W_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_act && n_walk * BLAS_WALK_NUM <= n_act * BLAS_WALK_DEN)) break;
-            if (walking) cur = wide_step<FMT>(lds_w, cur, ro, inv, relaxed(inv), sel, box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+            if (walking) { PH_T0; cur = wide_step<FMT>(lds_w, cur, ro, inv, relaxed(inv), sel, box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st); PH_ADD(1); }
 #if FW_WIDE_TWO_STEPS       // a second step per exit check (k_blas_lds gained 2 % from it on pair nodes)
-            if (act && !(cur & W_LEAF)) cur = wide_step<FMT>(lds_w, cur, ro, inv, relaxed(inv), sel, box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st);
+            if (act && !(cur & W_LEAF)) { PH_T0; cur = wide_step<FMT>(lds_w, cur, ro, inv, relaxed(inv), sel, box_tmin(TMIN, soft), TMAX, soft ? NO_CULL : cull_bound(have ? fminf(mbest, bt) : bt), st); PH_ADD(2); }
 #endif
         }
         // The round's triangle tests: the one put aside, then the one held.  A hit that would become the ray's best is a CANDIDATE; the
@@ -2330,6 +2380,7 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
             else if (act && (cur & W_LEAF) && cur != W_DONE) { item = cur & 0x7fffu; cur = st.sp ? st.pop() : W_DONE; }
             if (__ballot(item != W_DONE) == 0ull) continue;
             if (item != W_DONE) {
+                PH_T0;
                 const float4 *tp = (LDS_TRIS ? lds_tris : sc.tri) + 3 * (size_t)(tri_base + item);
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, b0, b1, b2;
@@ -2338,6 +2389,7 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
                         if (pass == 0) { ct0 = t; ci0 = item; } else { ct1 = t; ci1 = item; }
                     }
                 }
+                if (pass == 0) PH_ADD(3); else PH_ADD(4);
             }
         }
         if (ci1 != W_DONE && (ci0 == W_DONE || ct1 < ct0 || (ct1 == ct0 && sc.tri_rank[tri_base + ci1] > sc.tri_rank[tri_base + ci0]))) {
@@ -2348,18 +2400,23 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
             const bool want = ci != W_DONE && (!have || ct < mbest || (ct == mbest && sc.tri_rank[tri_base + ci] > sc.tri_rank[tri_base + mtri]));
             if (__ballot(want) == 0ull) continue;
             if (want) {
+                PH_T0;
                 const float4 *tp = (LDS_TRIS ? lds_tris : sc.tri) + 3 * (size_t)(tri_base + ci);
                 const float4 a = tp[0], b = tp[1], c = tp[2];
                 if (tri_gate_ok(sc, tri_base + ci, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), mk(c.x, c.y, c.z), ro, inv, TMIN, TMAX)) { have = true; mbest = ct; mtri = ci; }
+                PH_ADD(5);
             }
         }
         if (act && cur == W_DONE) {
+            PH_T0;
             const uint32_t bobj = bcode == MISS ? MISS : (bcode >> sc.prim_bits);
             if (have && (bobj == MISS || mbest < bt || (mbest == bt && sc.obj_rank[obj] > sc.obj_rank[bobj]))) { bt = mbest; bcode = (obj << sc.prim_bits) | mtri; }
             if (more) start_walk(park_next_mesh(more), qld(&park.ray_a[pidx]), qld(&park.ray_b[pidx]));      // the ray's next mesh (k_extend_scan's mask)
             else { qst(&hits[slot], make_float2(bt, __uint_as_float(bcode))); act = false; }
+            PH_ADD(6);
         }
     }
+    PH_FLUSH(0);
 }
 
 // k_extend_tlas_lds over WIDE_F32 nodes (scenes without meshes: part2's TLAS, random_spheres)
@@ -2411,6 +2468,7 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene
     V3 wo = mk(0, 0, 0), wd = wo, inv = wo;
     WideSel sel = wide_sel<WIDE_F32>(inv);
     LdsStackW st{stacks + (size_t)wib * levels * 64u + lane, 0};
+    PH_DECL;
     for (;;) {
         const unsigned long long idle_mask = __ballot(slot == IDLE);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
@@ -2439,23 +2497,26 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene
                 if (c_pos == c_n) {
                     ca = na; cb = nb; cs = ns; c_n = n_n; c_base = n_base; c_pos = 0;
                     if (c_n && bs.next(n_base, n_n)) fetch(n_base, n_n, na, nb, ns); else n_n = 0;
-                    prep_block();
+                    { PH_T0; prep_block(); PH_ADD(0); }
                 }
             }
         } else if (n_idle == 64u) break;
 
         const bool busy = slot != IDLE && cur != W_DONE;
         const uint32_t n_busy = (uint32_t)__popcll(__ballot(busy));
+        if (busy) PH_COUNT(7);
         for (;;) {
             const bool walking = busy && !(cur & W_LEAF);
             const uint32_t n_walk = (uint32_t)__popcll(__ballot(walking));
             if (n_walk == 0u || (n_walk < n_busy && n_walk * WALK_NUM <= n_busy * WALK_DEN)) break;
-            if (walking) cur = wide_step<WIDE_F32>(lds_w, cur, wo, inv, relaxed(inv), sel, box_tmin(TMIN, false), TMAX, cull_bound(have ? best_t : TMAX), st);
+            if (walking) { PH_T0; cur = wide_step<WIDE_F32>(lds_w, cur, wo, inv, relaxed(inv), sel, box_tmin(TMIN, false), TMAX, cull_bound(have ? best_t : TMAX), st); PH_ADD(1); }
         }
         if (busy && (cur & W_LEAF) && cur != W_DONE) {
+            PH_T0;
             const uint32_t item = cur & 0x7fffu;
             cur = st.sp ? st.pop() : W_DONE;
             Obj o = load_obj_for_hit(sc.obj, item);
+            { const uint32_t kd_ = obj_kind(o); if (kd_ == 0u) PH_COUNT(8); else if (kd_ == 4u) PH_COUNT(9); else if (kd_ == 6u) PH_COUNT(10); else PH_COUNT(11); }
             RngKey key{0, 0, 0};
             if (sc.has_medium) key = key_of(f, path_id);
             float t; uint32_t prim;
@@ -2463,10 +2524,12 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene
             if (hit_object<MEDIUM, 0, MEDIUM>(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)) {
                 if ((!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, item, wo, inv)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
             }
+            PH_ADD(3);
         }
         const bool done = slot != IDLE && cur == W_DONE;
-        if (done) { qst(&hits[slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits)); slot = IDLE; }
+        if (done) { PH_T0; qst(&hits[slot], pack_hit(best_t, best_obj, best_prim, sc.prim_bits)); slot = IDLE; PH_ADD(6); }
     }
+    PH_FLUSH(0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2879,7 +2942,7 @@ __device__ __forceinline__ bool expensive_shading(const DScene &sc, const float4
 template <bool CHEAP_ONLY = false, bool CHAIN = false>
 __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, const float4 *objp, const float4 *matp,
                                            const float4 *texp, const Ray &r, V3 beta, uint32_t chain, uint32_t path_id, float t_hit,
-                                           uint32_t hit_code, int segment, float4 *__restrict__ sample_rad, Ray &nr, V3 &nbeta, uint32_t &nchain) {
+                                           uint32_t hit_code, int segment, float4 *__restrict__ sample_rad, Ray &nr, V3 &nbeta, uint32_t &nchain PH_ARG) {
     bool alive = false;
     const uint32_t obj_index = hit_code == MISS ? MISS : (hit_code >> sc.prim_bits);
     V3 rad = mk(0.f, 0.f, 0.f);
@@ -2895,34 +2958,42 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
         return x;
     };
     if (obj_index == MISS) {
+        PH_T0;
         // render.rs:31; ColorEnv ignores the direction, so its normalisation (sqrt + 3 divisions) is skipped
         V3 dir = sc.env.kind == 0 ? r.d : normalized(r.d);
         if (CHEAP_ONLY) {      // ColorEnv or SkyEnv (environment.rs:21-26,60-67); an HdrEnvironment miss is an expensive case
             DEnv e = sc.env; if (e.kind == 2) e.kind = 0;
             rad = carried(env_sample(e, dir));
         } else rad = carried(env_sample(sc.env, dir));
+        PH_ADD(1);
     } else {
+        PH_T0;
         Obj o = load_obj(objp, obj_index);
         float4 m0 = matp[2 * o.material], m1 = matp[2 * o.material + 1];
         uint32_t mbits = __float_as_uint(m0.x), mkind = mbits & 0xffu, mtex = __float_as_uint(m0.y);
         bool need_uv = (mbits & MF_NEEDS_UV) != 0, tex_const = (mbits & MF_TEX_CONST) != 0;
         HitInfo h = rebuild_hit(sc, o, r, t_hit, hit_code & ((1u << sc.prim_bits) - 1u), need_uv, f.hit4 != 0u);
         V3 texc = mk(m1.x, m1.y, m1.z);                                      // inline ConstantTexture / Metal albedo
+        PH_ADD(2);
         // (the chain state exists only where every such texture is a constant — the host checks —, so its kernels carry no texture code)
-        if (!CHEAP_ONLY && !CHAIN && !tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point);
+        if (!CHEAP_ONLY && !CHAIN && !tex_const && (mkind == 0 || mkind == 3 || mkind == 4)) { PH_T0; texc = texture_sample(texp, sc.images, mtex, h.u, h.v, h.point); PH_ADD(3); }
         if (mkind == 3) {                                                      // EmissiveMat: emit, never scatters
+            PH_T0;
             rad = carried(texc);
+            PH_ADD(4);
         } else if (segment < 10) {                                             // render.rs:21
+            PH_T0;
+            if (mkind == 0) PH_COUNT(8); else if (mkind == 1) PH_COUNT(9); else if (mkind == 2) PH_COUNT(10); else PH_COUNT(12);
             RngKey key = key_of(f, path_id);
             V3 atten = texc;
             switch (mkind) {
             case 0: {                                                          // Lambertian material.rs:64-75
-                V3 target = h.point + h.normal + random_in_unit_sphere(key, segment);
+                V3 target = h.point + h.normal + random_in_unit_sphere(key, segment PH_PASS);
                 nr = Ray{h.point, target - h.point};
                 alive = true; break; }
             case 1: {                                                          // Metal material.rs:90-107
                 V3 reflected = reflect(r.d, h.normal);
-                nr = Ray{h.point, reflected + m0.z * random_in_unit_sphere(key, segment)};
+                nr = Ray{h.point, reflected + m0.z * random_in_unit_sphere(key, segment PH_PASS)};
                 alive = dot(nr.d, h.normal) > 0.f; break; }
             case 2: if (!CHEAP_ONLY) {                                         // Dielectric material.rs:121-151
                 float ref_idx = m0.w;
@@ -2940,17 +3011,19 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
                 if (!took_refraction) nr = Ray{h.point, reflected};
                 alive = true; } break;
             case 4: {                                                          // Isotropic material.rs:197-204
-                nr = Ray{h.point, random_in_unit_sphere(key, segment)};
+                nr = Ray{h.point, random_in_unit_sphere(key, segment PH_PASS)};
                 alive = true; break; }
             default: break;
             }
             if (CHAIN) nchain = chain | (o.material << (f.chain_bits * (uint32_t)segment));   // atten IS the material's constant (host: chain_bits)
             else nbeta = beta * atten;
+            PH_ADD(5);
         }
     }
     // every path deposits exactly once — except zeros over a black environment: k_raygen has already written them, densely
     // (adding +0 is exact, and most indoor paths end black; the scattered 16-byte deposits are k_shade's costliest stores)
     if (!alive && !(f.skip_zero_deposits && rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
+        PH_T0;
         // .w = the path's length in segments: k_accumulate sums it next to the colour, so accum.w of a pixel is its ray count
         // whenever every path deposits (any non-black environment, or FIREWORK_NO_ZERO_SKIP=1) — what tools/diverge.py
         // compares with the oracle's per-pixel counts to find a diverging path
@@ -2961,6 +3034,7 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
             const uint32_t b = f.dep_pixel_major ? dep_bit_of(f, path_id) : path_id;
             atomicOr(&f.dep_bits[b >> 5], 1u << (b & 31u));
         }
+        PH_ADD(6);
     }
     return alive;
 }
@@ -3007,6 +3081,7 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     const uint32_t base = w * q.cap;
     uint32_t out_n = 0;                                                  // survivors written so far (wave-uniform)
     uint32_t list_n = 0;                                                 // MODE 2: entries of shade_list (wave-uniform)
+    PH_DECL;
 // ---- K7: compaction inside the wave's private queue: ballot -> mbcnt prefix -> dense stores --------
     auto compact = [&](bool alive, const Ray &nr, V3 nbeta, uint32_t nchain, uint32_t path_id) {
         const unsigned long long mask = __ballot(alive);
@@ -3032,7 +3107,7 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
             const uint32_t i = base + shade_list[list_n - take + lane];
             const float4 ra = qld(&in.ray_a[i]), st = load_st(i); const float2 rb = load_ray_b(in, i, f, segment), hr = load_hit(i);
             path_id = __float_as_uint(st.w);
-            alive = shade_path<false, CHAIN>(sc, f, objp, matp, texp, make_ray(ra, rb, f, segment), mk(st.x, st.y, st.z), __float_as_uint(st.x), path_id, hr.x, __float_as_uint(hr.y), segment, sample_rad, nr, nbeta, nchain);
+            alive = shade_path<false, CHAIN>(sc, f, objp, matp, texp, make_ray(ra, rb, f, segment), mk(st.x, st.y, st.z), __float_as_uint(st.x), path_id, hr.x, __float_as_uint(hr.y), segment, sample_rad, nr, nbeta, nchain PH_PASS);
         }
         list_n -= take;
         compact(alive, nr, nbeta, nchain, path_id);
@@ -3048,14 +3123,16 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
         bool alive = false, later = false;
         Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0, nchain = 0;
         if (j < n) {
+            PH_T0;
             Ray r = make_ray(ra, rb, f, segment);
             V3 beta = mk(st.x, st.y, st.z);
             path_id = __float_as_uint(st.w);
             const uint32_t hit_code = __float_as_uint(hr.y);
             if (MODE == 2 && expensive_shading(sc, objp, matp, hit_code)) later = true;
-            else alive = shade_path<MODE != 0, CHAIN>(sc, f, objp, matp, texp, r, beta, __float_as_uint(st.x), path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta, nchain);
+            else alive = shade_path<MODE != 0, CHAIN>(sc, f, objp, matp, texp, r, beta, __float_as_uint(st.x), path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta, nchain PH_PASS);
+            PH_ADD(0);
         }
-        compact(alive, nr, nbeta, nchain, path_id);
+        { PH_T0; compact(alive, nr, nbeta, nchain, path_id); PH_ADD(7); }
         if (MODE == 2) {
             const unsigned long long lm = __ballot(later);
             if (lm) {
@@ -3068,6 +3145,7 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     }
     if (MODE == 2) while (list_n) run_list(min(list_n, 64u));
     if (lane == 0) q.wcount[(size_t)(segment + 1) * q.n_waves + w] = out_n;
+    PH_FLUSH(1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3162,7 +3240,8 @@ __global__ __launch_bounds__(WB) void k_bounce(DScene sc, DFrame f, DPaths in, D
                                         USE_BVH && sc.has_mesh && soft_ray(f.ex, r.d, sc.soft_shear));
             const uint32_t hit_code = best_obj == MISS ? MISS : ((best_obj << sc.prim_bits) | best_prim);
             uint32_t nchain = 0;
-            alive = shade_path(sc, f, objp, matp, texp, r, mk(st.x, st.y, st.z), 0u, path_id, best_t, hit_code, segment, sample_rad, nr, nbeta, nchain);
+            PH_DECL;
+            alive = shade_path(sc, f, objp, matp, texp, r, mk(st.x, st.y, st.z), 0u, path_id, best_t, hit_code, segment, sample_rad, nr, nbeta, nchain PH_PASS);
         }
         unsigned long long mask = __ballot(alive);
         uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -3571,6 +3650,14 @@ void preload_kernels() {
 #undef FW_TOUCH
     (void)hipGetLastError();
 }
+#ifdef FW_PHASE_STATS
+extern "C" int fw_debug_phase_stats(unsigned long long *out, int n) {   // debug builds only; reads and clears the sections' counters (3 per section)
+    static unsigned long long zero[2 * 3 * PH_N];
+    if (n < 2 * 3 * PH_N) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof zero) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof zero) == hipSuccess ? 2 * 3 * PH_N : -1;
+}
+#endif
 #ifdef FW_TRAV_STATS
 extern "C" int fw_debug_trav_stats(unsigned long long out[8]) {   // debug builds only; reads and clears the counters
     unsigned long long zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};

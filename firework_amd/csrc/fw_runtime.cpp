@@ -748,6 +748,7 @@ struct Flattener {
     bool wide_ok[2] = {true, true};
     std::vector<ShapeParams> mesh_cache;  // per shape index: a TriangleMesh shape referenced by several objects (or by a medium
     std::vector<uint8_t> mesh_cached;     // and an object) is flattened and built once, every user shares its triangles and BLAS
+    double ms_gather = 0, ms_ref = 0, ms_gate = 0, ms_sah = 0, ms_pair = 0, ms_wide = 0;   // where mesh_params spends its time (FIREWORK_TRACE=1, tools/big_mesh.py)
 
     int check_material(int32_t m) const { return (m < 0 || (uint32_t)m >= d->n_materials) ? FW_ERR_BAD_ARG : FW_OK; }
 
@@ -823,6 +824,8 @@ struct Flattener {
         max_tris = std::max(max_tris, n_tris);
         if ((uint64_t)tri_base + n_tris > fw::NODE_MASK) return fail(FW_ERR_UNSUPPORTED, "too many triangles");
         bool attr = s.normals || s.uvs;
+        auto tm = std::chrono::steady_clock::now();
+        auto lap = [&](double &acc) { const auto t = std::chrono::steady_clock::now(); acc += std::chrono::duration<double, std::milli>(t - tm).count(); tm = t; };
         std::vector<Box> boxes(n_tris);
         tri.resize(tri.size() + (size_t)n_tris * 12);
         if (attr) any_attr = true;
@@ -848,6 +851,7 @@ struct Flattener {
             if (std::fabs(size.z) < 0.001f) { b.mn.z -= 0.001f; b.mx.z += 0.001f; }
             boxes[t] = b;
         }
+        lap(ms_gather);
         FlatBvh local;
         try { sp.box = bvh_build(local, boxes); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
         {   // ties are resolved by the reference tree's in-order rank, whatever tree is traversed
@@ -858,6 +862,7 @@ struct Flattener {
         sp.ref_root = (uint32_t)(ref_blas.size() / 8); sp.n_tris = n_tris;
         ref_blas.insert(ref_blas.end(), local.nodes.begin(), local.nodes.end());
         ref_blas_depth = std::max(ref_blas_depth, local.depth);
+        lap(ms_ref);
         // Round 4: the reference tests a triangle iff the ray passes every box down to its LEAF NODE, i.e. iff it passes that node's box
         // (bvh.rs:44-52: a DoubleLeaf's two triangles sit behind the union; the ancestors' boxes are supersets under the monotone slab
         // arithmetic).  The walked trees keep the triangles' own, tight boxes — walking the unions costs 30 % (gpurun_out/r04d) — and
@@ -876,9 +881,12 @@ struct Flattener {
             const float typ = box_extent(sp.box) / std::sqrt((float)std::max(1u, n_tris));
             for (Box &b : boxes) b = grown_by(b, std::fmax(std::ldexp(typ, -6), std::ldexp(box_extent(b), -14)));
         }
+        lap(ms_gate);
         if (use_sah()) { FlatBvh sah; sah_build(sah, boxes); local = std::move(sah); }
+        lap(ms_sah);
         uint32_t root = pair_convert(local, boxes, blas);     // root reference into the shared BLAS array
         blas_depth = blas.depth;
+        lap(ms_pair);
         sp.aux0 = root; sp.aux1 = tri_base;
         for (int f = 0; f < 2; f++) {                         // the same tree as WIDE nodes, in both encodings (create_scene_impl keeps one, or none)
             WideBvh &wb = f == 0 ? wblas_f32 : wblas_q8;
@@ -888,6 +896,7 @@ struct Flattener {
             if (wr == 0xffffffffu) wide_ok[f] = false;
             (f == 0 ? sp.wroot_f32 : sp.wroot_q8) = wr;
         }
+        lap(ms_wide);
         if (s.normals) sp.flags |= fw::OF_MESH_NORMALS;
         if (attr) sp.flags |= fw::OF_MESH_ATTR;
         return FW_OK;
@@ -1239,6 +1248,8 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     }
     if (trace) fprintf(stderr, "[firework] scene_create: build %.2f ms, blob %.2f ms (%zu B), alloc %.2f ms (%s), upload launch %.2f ms\n",
                        tr_build, tr_blob, total, tr_alloc, reused ? "cached" : "hipMalloc", ms_since(tr3));
+    if (trace && !fl.tri.empty()) fprintf(stderr, "[firework] scene_create: meshes (%zu triangles): gather %.2f ms | reference tree + ranks %.2f | gate boxes %.2f | SAH %.2f | pair nodes %.2f | wide nodes (f32 + q8) %.2f\n",
+                                          fl.tri.size() / 12, fl.ms_gather, fl.ms_ref, fl.ms_gate, fl.ms_sah, fl.ms_pair, fl.ms_wide);
     if (rc) { delete sc; return rc; }
     const uint8_t *base = (const uint8_t *)sc->data.p;
     fw::DScene &d = sc->d;

@@ -15,7 +15,7 @@ def grid_mesh(n, material):
     idx = np.stack([a, b, c, b, d, c], -1).reshape(-1).astype(np.uint32)
     return TriangleMesh.new(verts, idx, None, None, material)
 
-for n in (101, 317, 709):
+for n in [int(x) for x in os.environ.get("BIG_MESH_N", "101,317,709").split(",")]:      # 20 k, 200 k, 1 M triangles; FIREWORK_TRACE=1 splits scene creation
     sc = Scene.new()
     m = sc.add_material(LambertianMat.with_color((0.7, 0.6, 0.5)))
     mesh = grid_mesh(n, m)
