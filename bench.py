@@ -130,6 +130,8 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    from firework_amd import _lib
+    _lib.init(device_index)        # fw_init: context, code objects, kernel handles and the default path arena — explicit since ABI v7, before any timed region
     scene, renderer = scenes.config(args.config, args.width, args.height, args.spp)
     if args.paths_per_batch:
         renderer.paths_per_batch(args.paths_per_batch)
@@ -310,32 +312,47 @@ def device_info(device_index):
 
 
 def one_shot_cold(args):
-    """The region main.rs:40-44 times, in the state the reference's binary is in when it times it: a process's FIRST call.  A
-    fresh child process renders the frame once (code-object load, pool allocation, scene creation, render, D2H) and reports it."""
-    code = ("import sys, time, json; sys.path.insert(0, %r)\n"
-            "from firework_amd import scenes, _lib\n"
-            "s, r = scenes.config(%r, %r, %r, %r); sd = s.to_desc()\n"
-            "t0 = time.perf_counter(); _lib.load(); load_ms = (time.perf_counter() - t0) * 1e3\n"
-            "t0 = time.perf_counter(); res = _lib.render_scene(sd, r); dt = (time.perf_counter() - t0) * 1e3\n"
-            "st = res.stats\n"
-            "out = dict(ms_wall=dt, ms_library=st['ms_wall'], ms_scene=st['ms_scene'], ms_render=st['ms_render'], ms_d2h=st['ms_d2h'], mrays_per_s=st['rays'] / dt / 1e3, ms_library_load=load_ms)\n"
-            "seq = []\n"
-            "for name in (%r):\n"
-            "    s2, r2 = scenes.config(name); sd2 = s2.to_desc(); w = []\n"
-            "    for rep in range(3):\n"
-            "        t0 = time.perf_counter(); _lib.render_scene(sd2, r2); w.append((time.perf_counter() - t0) * 1e3)\n"
-            "    seq.append(dict(config=name, first_ms=w[0], warm_ms=min(w[1:]), first_over_warm=w[0] / min(w[1:])))\n"
-            "out['then_first_calls_in_the_same_process'] = seq\n"
-            "print(json.dumps(out))\n"
-            % (ROOT, args.config, args.width, args.height, args.spp, ("C3_suzanne", "C4b_volume_test") if args.config == "C2_cornell_box" and not args.spp else ()))
-    try:
+    """The region main.rs:40-44 times, in the state the reference's binary is in when it times it: a process's FIRST call.  Two fresh
+    child processes render the frame once each: one the way the CLI and this bench do (fw_init first, then the call), one the way a host
+    that never heard of fw_init does (the first call initialises the device itself).  Every part is reported; `ms_cold_total` = library
+    load + fw_init + first call is what a fresh `python -m firework_amd` user waits for beyond the interpreter's own imports."""
+    def child(with_init):
+        code = ("import sys, time, json; sys.path.insert(0, %r)\n"
+                "from firework_amd import scenes, _lib\n"
+                "s, r = scenes.config(%r, %r, %r, %r); sd = s.to_desc()\n"
+                "t0 = time.perf_counter(); _lib.load(); load_ms = (time.perf_counter() - t0) * 1e3\n"
+                "init_ms = 0.0\n"
+                "if %r:\n"
+                "    t0 = time.perf_counter(); _lib.init(0); init_ms = (time.perf_counter() - t0) * 1e3\n"
+                "t0 = time.perf_counter(); res = _lib.render_scene(sd, r); dt = (time.perf_counter() - t0) * 1e3\n"
+                "st = res.stats\n"
+                "out = dict(ms_wall=dt, ms_library=st['ms_wall'], ms_scene=st['ms_scene'], ms_render=st['ms_render'], ms_d2h=st['ms_d2h'], mrays_per_s=st['rays'] / dt / 1e3,\n"
+                "           ms_library_load=load_ms, ms_fw_init=init_ms, ms_cold_total=load_ms + init_ms + dt)\n"
+                "seq = []\n"
+                "for name in (%r):\n"
+                "    s2, r2 = scenes.config(name); sd2 = s2.to_desc(); w = []\n"
+                "    for rep in range(3):\n"
+                "        t0 = time.perf_counter(); _lib.render_scene(sd2, r2); w.append((time.perf_counter() - t0) * 1e3)\n"
+                "    seq.append(dict(config=name, first_ms=w[0], warm_ms=min(w[1:]), first_over_warm=w[0] / min(w[1:])))\n"
+                "out['then_first_calls_in_the_same_process'] = seq\n"
+                "print(json.dumps(out))\n"
+                % (ROOT, args.config, args.width, args.height, args.spp, with_init,
+                   ("C3_suzanne", "C4b_volume_test") if with_init and args.config == "C2_cornell_box" and not args.spp else ()))
         cp = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, FIREWORK_TRACE="1"))
         d = json.loads([l for l in cp.stdout.splitlines() if l.startswith("{")][-1])
         d["trace"] = [l for l in cp.stderr.splitlines() if l.startswith("[firework]")][:12]     # where the first call's host time went (FIREWORK_TRACE)
-        d["region"] = ("first fw_render_scene call of a fresh process: wall = scene + render + D2H; the library's load (ms_library_load: HIP context, "
-                       "code objects, staging and the path arena — its static initialiser; the arena's hipMalloc takes 0.4 ms to 1.4 s by the state of the "
-                       "device's memory) comes before it, like the loading of the reference's binary; then the first calls of two "
-                       "other configs in the same process (the arena may have to grow)")
+        return d
+    try:
+        d = child(True)
+        d["region"] = ("first fw_render_scene call of a fresh process after fw_init: ms_wall = scene + render + D2H; before it ms_library_load (dlopen: no HIP call since "
+                       "ABI v7) and ms_fw_init (HIP context, code objects, kernel handles, staging, the default path arena: 0.4 ms to 1.4 s by the state of the "
+                       "device's memory); ms_cold_total = all three; then the first calls of two other configs in the same process")
+        try:
+            lazy = child(False)
+            d["without_fw_init"] = {k: lazy[k] for k in ("ms_wall", "ms_library_load", "ms_cold_total", "ms_render", "ms_scene", "trace")}
+            d["without_fw_init"]["region"] = "the same first call in a process that never calls fw_init: the call initialises the device itself and sizes the arena for this frame"
+        except Exception as e:
+            d["without_fw_init"] = {"error": repr(e)}
         return d
     except Exception as e:
         return {"error": repr(e)}
@@ -407,8 +424,12 @@ def roofline_objects(acc, args, tr, renderer, steps=None):
     ach = shd_bytes / shd_s / 1e9 if shd_s > 0 else 0.0
     if traffic is not None and shd_s > 0:
         frac_traffic = traffic * n_sh / shd_s / 1e9 / HBM_PEAK_GBS
+    # what bounds k_shade: the SQ counters of THIS build where a summary exists (scripts/summarize_prof.py: the larger of the measured
+    # utilisations when it reaches 0.7, else "latency"); "hbm" by kernel class only when there is none, and the line says so
     res["roofline"] = {
-        "bound": "hbm", "kernel": "k_shade", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+        "bound": shade_bound["counters"] if shade_bound else "hbm",
+        "bound_source": shade_bound["source"] if shade_bound else "default by kernel class (k_shade streams the queue arrays); no counter summary of this build and workload under profiles/",
+        "kernel": "k_shade", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": traffic_src, "frac_traffic": frac_traffic,
         "algorithmic_bytes_per_launch": shd_bytes / n_sh, "avg_launch_us": shd_s * 1e6 / n_sh,
         "bytes_per_ray": shd_bytes / max(1.0, float(exact["rays"])),
@@ -475,17 +496,31 @@ def cpu_baseline(args, s, cores):
     from firework_amd import scenes
     from firework_amd._abi import FW_RNG_LCG
     from oracle import oracle_binding as ob       # CPU oracle: the checker, timed as the reported baseline
-    # bounded sample: ~15 s of CPU work at ~0.55 Msamples/s per core on this scene
+    # bounded sample: ~15 s of CPU work at ~0.55 Msamples/s per core on this scene, split between the two builds below
     cpu_spp = args.cpu_spp or max(16, min(s["samples"], int(15.0 * 0.55e6 * cores / (s["width"] * s["height"]))))
-    cscene, cr = scenes.config(args.config, args.width, args.height, cpu_spp)
-    c0 = time.perf_counter()
-    cres = ob.render(cscene, cr, rng_mode=FW_RNG_LCG, n_threads=cores)   # reference semantics: per-pixel sequential LCG
-    cdt = time.perf_counter() - c0
-    return {"value": cres.stats["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "msamples_per_s": cres.stats["samples"] / cdt / 1e6,
-            "timed_region": "scene conversion + BVH build + render (main.rs:40-44), C++ restatement of the reference's rayon loop",
-            "sample": f"{args.config} {cr.settings['width']}x{cr.settings['height']} @{cpu_spp}spp "
-                      f"({cres.stats['samples']} samples, {cdt:.1f} s; cost is linear in spp)"}
+    native = ob.native_timing_build()             # the same source at -O3 -march=native, built on this host: timed only, never the checker
+    def timed(spp, timing_lib=None):
+        cscene, cr = scenes.config(args.config, args.width, args.height, spp)
+        c0 = time.perf_counter()
+        cres = ob.render(cscene, cr, rng_mode=FW_RNG_LCG, n_threads=cores, timing_lib=timing_lib)   # reference semantics: per-pixel sequential LCG
+        cdt = time.perf_counter() - c0
+        return cres, cr, cdt
+    half = max(8, cpu_spp // 2) if native else cpu_spp
+    cres, cr, cdt = timed(half)
+    out = {"value": cres.stats["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "msamples_per_s": cres.stats["samples"] / cdt / 1e6,
+           "build": "oracle/liboracle.so: -O2 -ffp-contract=off -mfma (the checker's build)",
+           "timed_region": "scene conversion + BVH build + render (main.rs:40-44), C++ restatement of the reference's rayon loop",
+           "sample": f"{args.config} {cr.settings['width']}x{cr.settings['height']} @{half}spp "
+                     f"({cres.stats['samples']} samples, {cdt:.1f} s; cost is linear in spp)"}
+    if native:
+        nres, ncr, ndt = timed(half, native)
+        checker = dict(value=out["value"], msamples_per_s=out["msamples_per_s"], build=out["build"], sample=out["sample"])
+        out.update(value=nres.stats["rays"] / ndt / 1e6, msamples_per_s=nres.stats["samples"] / ndt / 1e6,
+                   build="the same source at -O3 -march=native -ffp-contract=off, built on this host for this leg only (never the checker)",
+                   sample=f"{args.config} {ncr.settings['width']}x{ncr.settings['height']} @{half}spp ({nres.stats['samples']} samples, {ndt:.1f} s; cost is linear in spp)",
+                   checker_build=checker)
+    return out
 
 
 def parity(args, tr, renderer, scene, frame_u8, cpu, cores):
@@ -496,7 +531,7 @@ def parity(args, tr, renderer, scene, frame_u8, cpu, cores):
     from oracle import oracle_binding as ob
     s = renderer.settings
     w, h, spp = s["width"], s["height"], s["samples"]
-    est = w * h * spp / max(1e-9, cpu["msamples_per_s"] * 1e6)          # seconds for every pixel at the measured CPU rate
+    est = w * h * spp / max(1e-9, (cpu.get("checker_build") or cpu)["msamples_per_s"] * 1e6)          # seconds for every pixel at the checker build's measured rate
     stride = 1
     while est / (stride * stride) > args.parity_seconds:
         stride += 1

@@ -38,6 +38,7 @@ int main(int argc, char **argv) {
     size_t width = argc > 3 ? strtoul(argv[1], nullptr, 10) : 300, height = argc > 3 ? strtoul(argv[2], nullptr, 10) : 300,
            samples = argc > 3 ? strtoul(argv[3], nullptr, 10) : 1000;
     Scene scene = cornell_box();
+    try { init(); } catch (const std::exception &e) { std::fprintf(stderr, "init failed: %s\n", e.what()); return 1; }   // fw_init: not part of the reference's timed region
     auto start = std::chrono::steady_clock::now();
 
     CameraSettings camera = CameraSettings::default_().cam_pos({278.f, 278.f, -800.f}).look_at({278.f, 278.f, 0.f}).field_of_view(40.f);

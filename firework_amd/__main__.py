@@ -26,8 +26,11 @@ def main(argv=None):
     ap.add_argument("--checkpoint", default=None, metavar="FILE", help=".npz accumulation checkpoint: written after every pass, resumed from if present")
     opt = ap.parse_args(argv)
 
+    from . import _lib
     from .api import CameraSettings, Renderer, save_image
     from .yaml_io import load_scene
+
+    _lib.init(opt.device)      # fw_init: context, code objects and the path arena before the timed region, like the loading of the reference's binary (main.rs:40)
 
     scene = load_scene(opt.scene_file)
     camera = CameraSettings.default().cam_pos((0.0, 30.0, 50.0)).look_at((0.0, 0.0, 0.0)).field_of_view(40.0)

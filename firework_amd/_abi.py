@@ -1,7 +1,8 @@
 """ctypes mirror of include/firework_hip.h (the C ABI).  Field order and types must match the header."""
 import ctypes as C
 
-FW_ABI_VERSION = 6
+FW_ABI_VERSION = 7
+FW_INIT_NO_ARENA = 0xFFFFFFFFFFFFFFFF   # fw_init: no path arena (the first render sizes its own)
 FW_MAX_SEGMENTS = 11
 
 # fw_status

@@ -22,11 +22,15 @@ class FireworkError(RuntimeError):
         super().__init__(f"firework_hip error {status}: {detail}")
 
 
-def load():
+def load(preload=False, device=None):
     """Load the native library once.  torch is imported first so that the process holds exactly one
-    HIP runtime (torch bundles libamdhip64.so.7; our library's DT_NEEDED resolves to that copy)."""
+    HIP runtime (torch bundles libamdhip64.so.7; our library's DT_NEEDED resolves to that copy).
+    Loading makes no HIP call (ABI v7).  preload=True also runs fw_init on `device` (default: LOCAL_RANK's, else 0) — context, code
+    objects, kernel handles and the default path arena — which is what the CLI and bench.py want before their timed regions."""
     global _lib
     if _lib is not None:
+        if preload:
+            init(device)
         return _lib
     if not os.path.exists(LIB_PATH):
         raise FireworkError(A.FW_ERR_NO_DEVICE, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`"
@@ -65,10 +69,25 @@ def load():
     lib.fw_set_option.argtypes = [C.c_char_p, C.c_char_p]
     lib.fw_selftest_wide_bvh.restype = C.c_int
     lib.fw_selftest_wide_bvh.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.fw_init.restype = C.c_int
+    lib.fw_init.argtypes = [C.c_int, C.c_uint64]
     if lib.fw_abi_version() != A.FW_ABI_VERSION:
         raise FireworkError(A.FW_ERR_BAD_ARG, "ABI version mismatch between _abi.py and libfirework_hip.so")
     _lib = lib
+    if preload:
+        init(device)
     return lib
+
+
+def init(device=None, arena_bytes=0):
+    """fw_init: explicit, idempotent initialisation of one device (default: LOCAL_RANK's, else 0).  arena_bytes 0 = the default
+    arena, A.FW_INIT_NO_ARENA = none."""
+    lib = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0") or 0)
+        if device >= max(1, lib.fw_device_count()):
+            device = 0
+    _check(lib, lib.fw_init(int(device), int(arena_bytes)))
 
 
 def _check(lib, st):

@@ -2942,7 +2942,8 @@ __device__ __forceinline__ bool expensive_shading(const DScene &sc, const float4
 template <bool CHEAP_ONLY = false, bool CHAIN = false>
 __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, const float4 *objp, const float4 *matp,
                                            const float4 *texp, const Ray &r, V3 beta, uint32_t chain, uint32_t path_id, float t_hit,
-                                           uint32_t hit_code, int segment, float4 *__restrict__ sample_rad, Ray &nr, V3 &nbeta, uint32_t &nchain PH_ARG) {
+                                           uint32_t hit_code, int segment, float4 *__restrict__ sample_rad, Ray &nr, V3 &nbeta, uint32_t &nchain PH_ARG,
+                                           const RngKey *pre_key = nullptr) {      // pre_key: the path's RNG key, when the caller has fetched it already (k_shade, FW_SHADE_PIPE)
     bool alive = false;
     const uint32_t obj_index = hit_code == MISS ? MISS : (hit_code >> sc.prim_bits);
     V3 rad = mk(0.f, 0.f, 0.f);
@@ -2962,8 +2963,14 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
         // render.rs:31; ColorEnv ignores the direction, so its normalisation (sqrt + 3 divisions) is skipped
         V3 dir = sc.env.kind == 0 ? r.d : normalized(r.d);
         if (CHEAP_ONLY) {      // ColorEnv or SkyEnv (environment.rs:21-26,60-67); an HdrEnvironment miss is an expensive case
-            DEnv e = sc.env; if (e.kind == 2) e.kind = 0;
-            rad = carried(env_sample(e, dir));
+            // (spelled out on sc.env's own fields: through a modified COPY of the struct the colour came back as a per-lane vector load from
+            // the kernel-argument segment — a global load in the middle of k_shade's chunk, which on gfx9's in-order vmcnt completes the next
+            // chunk's prefetch with it, round 5)
+            if (sc.env.kind == 1) {
+                const float t = 0.5f * (dir.y + 1.0f);
+                rad = carried((1.f - t) * mk(sc.env.horizon[0], sc.env.horizon[1], sc.env.horizon[2]) + t * mk(sc.env.zenith[0], sc.env.zenith[1], sc.env.zenith[2]));
+            } else if (!f.skip_zero_deposits) rad = carried(mk(sc.env.color[0], sc.env.color[1], sc.env.color[2]));
+            // else: a black ColorEnv (the host checked): the path carries nothing, whatever it scattered on, and writes no record (below)
         } else rad = carried(env_sample(sc.env, dir));
         PH_ADD(1);
     } else {
@@ -2984,7 +2991,7 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
         } else if (segment < 10) {                                             // render.rs:21
             PH_T0;
             if (mkind == 0) PH_COUNT(8); else if (mkind == 1) PH_COUNT(9); else if (mkind == 2) PH_COUNT(10); else PH_COUNT(12);
-            RngKey key = key_of(f, path_id);
+            RngKey key = pre_key ? *pre_key : key_of(f, path_id);
             V3 atten = texc;
             switch (mkind) {
             case 0: {                                                          // Lambertian material.rs:64-75
@@ -3059,6 +3066,12 @@ template <int LDS_TAB, int MODE, bool CHAIN>   // CHAIN: 8-byte state (load_stat
 #ifndef FW_SHADE_WAVES
 #define FW_SHADE_WAVES 5
 #endif
+#ifndef FW_SHADE_PIPE
+#define FW_SHADE_PIPE 0            // the vmcnt-aware order of k_shade's loop (gathers, then prefetch, then shading, then stores by every lane)
+#endif
+#ifndef FW_SHADE_STATIC_STORES
+#define FW_SHADE_STATIC_STORES FW_SHADE_PIPE
+#endif
 __attribute__((amdgpu_waves_per_eu(FW_SHADE_WAVES, 8)))
 __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DPaths out, const float2 *__restrict__ hits,
                                                  float4 *__restrict__ sample_rad, DQueue q, int segment,
@@ -3083,9 +3096,25 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     uint32_t list_n = 0;                                                 // MODE 2: entries of shade_list (wave-uniform)
     PH_DECL;
 // ---- K7: compaction inside the wave's private queue: ballot -> mbcnt prefix -> dense stores --------
-    auto compact = [&](bool alive, const Ray &nr, V3 nbeta, uint32_t nchain, uint32_t path_id) {
+    auto compact = [&](bool alive, const Ray &nr, V3 nbeta, uint32_t nchain, uint32_t path_id, uint32_t c0 = 0xffffffffu) {
         const unsigned long long mask = __ballot(alive);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+#if FW_SHADE_STATIC_STORES
+        // Round 5: EVERY lane stores, the dead ones into slots of the wave's own output window that no survivor of this chunk can take and
+        // that a later chunk overwrites or nobody reads (position c0 + 64 + lane >= out_n + 64, clamped to the window's last slot, which a
+        // survivor reaches only when all 64 lanes survive).  Why: on gfx9 loads and stores share ONE in-order counter (vmcnt), and with the
+        // stores behind `if (alive)` — a branch the wave may skip — the compiler cannot know how many of them follow the next chunk's
+        // prefetch loads, so the loop-top wait for those loads was `s_waitcnt vmcnt(0)`: every chunk of every wave waited for the L2's
+        // acknowledgement of its own stores (54 % of k_shade's wave time in s_waitcnt, profiles/r04z_c2_sq.json).  With a static store count
+        // the wait is vmcnt(3): the loads, nothing younger.
+        if (c0 != 0xffffffffu) {
+            const uint32_t dst = base + (alive ? out_n + rank : min(c0 + 64u + lane, q.cap - 1u));
+            qst(&out.ray_a[dst], make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x));
+            qst(&out.ray_b[dst], make_float2(nr.d.y, nr.d.z));
+            if (CHAIN) qst(&reinterpret_cast<float2 *>(out.state)[dst], make_float2(__uint_as_float(nchain), __uint_as_float(path_id)));
+            else qst(&out.state[dst], make_float4(nbeta.x, nbeta.y, nbeta.z, __uint_as_float(path_id)));
+        } else
+#endif
         if (alive) {
             const uint32_t dst = base + out_n + rank;
             qst(&out.ray_a[dst], make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x));
@@ -3114,12 +3143,56 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
     };
     // software pipeline: next chunk's ray / state / hit are in flight while the current chunk is shaded
     float4 ra_n = make_float4(0, 0, 0, 0), st_n = ra_n; float2 rb_n = make_float2(0, 0), hr_n = rb_n;
+#if FW_SHADE_PIPE
+    // Round 5: what the prefetch really needs on gfx9.  Loads and stores share ONE in-order counter (vmcnt): waiting for a load means
+    // waiting for everything issued before it, and a wait's immediate is the number of YOUNGER operations that may stay outstanding — which
+    // the compiler can only use when that number is the same on every path.  The loop used to issue the next chunk's loads at its top
+    // behind `if (j + 64 < n)`, gather the path's pixel id (key_of) in the middle and store the survivors behind `if (alive)`: the gather's
+    // wait (vmcnt(0): in-order) completed the prefetch a few hundred instructions after it was issued, and the next top's wait (vmcnt(0):
+    // unknown store count) completed the stores — every chunk of every wave sat out an HBM round trip and an L2 write acknowledgement
+    // (54 % of the wave time in s_waitcnt at 0.79 instruction issue, profiles/r04z_c2_sq.json; fewer instructions or a deeper prefetch
+    // changed nothing: DESIGN §5 rounds 1-4).  Now: (A) the chunk's dependent gathers are issued FIRST (the pixel id), (B) then the next
+    // chunk's loads, always the same four instructions (indices clamped to the queue's last entry, and where a stream is not read at all —
+    // segment-0 state, ray_b of pinhole camera rays — one hot address stands in), (C) the shading, (D) the stores, every lane
+    // (FW_SHADE_STATIC_STORES).  The waits become vmcnt(4) for the gather and vmcnt(3) at the top.
+    auto prefetch = [&](uint32_t jn) {       // jn: queue position, clamped by the caller
+        const uint32_t in_ = base + jn;
+        ra_n = qld(&in.ray_a[in_]);
+        rb_n = qld(&in.ray_b[short_rays(f, segment) ? base : in_]);
+        if (CHAIN) { const float2 v = qld(&reinterpret_cast<const float2 *>(in.state)[segment == 0 ? base : in_]); st_n = make_float4(v.x, 0.f, 0.f, v.y); }
+        else st_n = qld(&in.state[segment == 0 ? base : in_]);
+        hr_n = load_hit(in_);
+    };
+    auto fix_implicit = [&](float4 &st_, float2 &rb_, uint32_t slot) {      // the streams that are not stored at segment 0 (load_state*, load_ray_b)
+        if (segment == 0) st_ = CHAIN ? make_float4(0.f, 0.f, 0.f, __uint_as_float(slot)) : make_float4(1.f, 1.f, 1.f, __uint_as_float(slot));
+        if (short_rays(f, segment)) rb_ = make_float2(0.f, 0.f);
+    };
+    if (n) {
+        prefetch(min(lane, n - 1u));
+        // ... and the loop is entered with the same operations behind the first chunk's loads as every later trip has behind its own: three
+        // stores (here into the first 64 output slots, which chunk 0's survivors overwrite or nobody reads) — the wait at the top of the loop
+        // is compiled once, for the entry and for the back edge, with the smaller of the two counts
+        const uint32_t d0 = base + lane;
+        qst(&out.ray_a[d0], make_float4(0.f, 0.f, 0.f, 0.f));
+        qst(&out.ray_b[d0], make_float2(0.f, 0.f));
+        if (CHAIN) qst(&reinterpret_cast<float2 *>(out.state)[d0], make_float2(0.f, 0.f)); else qst(&out.state[d0], make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+#else
     if (lane < n) { ra_n = qld(&in.ray_a[base + lane]); rb_n = load_ray_b(in, base + lane, f, segment); st_n = load_st(base + lane); hr_n = load_hit(base + lane); }
+#endif
     for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
         const uint32_t j = c0 + lane;
         const uint32_t i = base + j;
         float4 ra = ra_n, st = st_n; float2 rb = rb_n, hr = hr_n;
+#if FW_SHADE_PIPE
+        fix_implicit(st, rb, i);
+        const RngKey key_ = key_of(f, __float_as_uint(st.w));        // (A) the chunk's own gather, before (B) the prefetch
+        prefetch(min(j + 64u, n - 1u));
+        const RngKey *pre_key = &key_;
+#else
         if (j + 64u < n) { ra_n = qld(&in.ray_a[i + 64u]); rb_n = load_ray_b(in, i + 64u, f, segment); st_n = load_st(i + 64u); hr_n = load_hit(i + 64u); }
+        const RngKey *pre_key = nullptr;
+#endif
         bool alive = false, later = false;
         Ray nr{mk(0, 0, 0), mk(0, 0, 0)}; V3 nbeta = mk(0, 0, 0); uint32_t path_id = 0, nchain = 0;
         if (j < n) {
@@ -3129,10 +3202,10 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
             path_id = __float_as_uint(st.w);
             const uint32_t hit_code = __float_as_uint(hr.y);
             if (MODE == 2 && expensive_shading(sc, objp, matp, hit_code)) later = true;
-            else alive = shade_path<MODE != 0, CHAIN>(sc, f, objp, matp, texp, r, beta, __float_as_uint(st.x), path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta, nchain PH_PASS);
+            else alive = shade_path<MODE != 0, CHAIN>(sc, f, objp, matp, texp, r, beta, __float_as_uint(st.x), path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta, nchain PH_PASS, pre_key);
             PH_ADD(0);
         }
-        { PH_T0; compact(alive, nr, nbeta, nchain, path_id); PH_ADD(7); }
+        { PH_T0; compact(alive, nr, nbeta, nchain, path_id, c0); PH_ADD(7); }
         if (MODE == 2) {
             const unsigned long long lm = __ballot(later);
             if (lm) {

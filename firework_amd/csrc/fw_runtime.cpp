@@ -612,7 +612,9 @@ struct Workspace {
     hipEvent_t ev_upload = nullptr;       // after the latest scene upload on this device: renders wait for it in stream order
     hipStream_t upload_stream = nullptr;  // the upload kernel's own non-blocking stream: a launch on the legacy NULL stream would
                                           // synchronise with every blocking stream of the process (torch's default stream included)
+    bool inited = false;                  // init_device_locked has run on this device (fw_init, or the first call that needed the device)
     void release() {
+        inited = false;
         if (ev_d2h) { (void)hipEventDestroy(ev_d2h); ev_d2h = nullptr; }
         if (ev_upload) { (void)hipEventSynchronize(ev_upload); (void)hipEventDestroy(ev_upload); ev_upload = nullptr; }
         if (upload_stream) { (void)hipStreamDestroy(upload_stream); upload_stream = nullptr; }
@@ -654,55 +656,58 @@ int device_cus(int device) {
     return cu_cache[device];
 }
 
-// ---- preload (round 4).  A process's first call used to pay, inside the caller's timed region (main.rs:40-44), for things that are
-// no part of any frame: the HIP context, the device query, the load of this library's code objects (its first kernel launch), the
-// pinned staging buffer, the upload stream — 150-180 ms of the 213 ms of a cold cornell frame (profiles/r03z_oneshot_trace.txt).
-// They now happen when the library is LOADED, like the loading of the executable itself, which the reference does not time either:
-// a static initialiser warms the device this process will use (LOCAL_RANK where a launcher set it, else device 0).
-// FIREWORK_NO_PRELOAD=1 (environment, read here) keeps the library from touching the GPU before its first call.
-void warm_device(int dev) {
-    if (hipSetDevice(dev) != hipSuccess) return;
-    if (device_cus(dev) <= 0) return;
-    Workspace *ws = workspace_for(dev);
-    if (!ws) return;
-    std::lock_guard<std::mutex> g(ws->mu);
-    if (!ws->staging && hipHostMalloc(&ws->staging, 1 << 20, hipHostMallocDefault) == hipSuccess) ws->staging_bytes = 1 << 20;
-    if (!ws->upload_stream && hipStreamCreateWithFlags(&ws->upload_stream, hipStreamNonBlocking) != hipSuccess) ws->upload_stream = nullptr;
-    if (!ws->ev_upload && hipEventCreateWithFlags(&ws->ev_upload, hipEventDisableTiming) != hipSuccess) ws->ev_upload = nullptr;
-    for (int l = 0; l < 2; l++) if (!ws->lanes[l].stream && hipStreamCreateWithFlags(&ws->lanes[l].stream, hipStreamNonBlocking) != hipSuccess) ws->lanes[l].stream = nullptr;
-    if (!ws->staging || !ws->upload_stream) return;
-    // The path arena too (render_impl carves every lane buffer out of it).  Its hipMalloc is lazy on a device whose memory is clean (0.4 ms
-    // for 64 GiB) and is NOT where the driver has to clear the pages first: 187 ms and 1 448 ms were measured for the same call on two
-    // other boxes of the pool (gpurun_out/r04z/bench.json, `one_shot_cold.trace`) — inside a first frame that renders in 38 ms.  Pools are
-    // no part of any frame: they are made here, with the context and the code objects.
-    {
-        size_t free_b = 0, total_b = 0;
-        if (!ws->arena.p && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t want = std::min<size_t>((size_t)64 << 30, free_b / 3) & ~(((size_t)1 << 30) - 1);
-            if (want >= ((size_t)1 << 30) && ws->arena.alloc(want) != FW_OK) { (void)hipGetLastError(); g_last_error.clear(); }
-        }
-    }
+// ---- initialisation (round 5: fw_init).  A process's first call pays for things that are no part of any frame: the HIP context, the
+// device query, the load of this library's code objects (its first kernel launch), every kernel's first resolution, the pinned
+// staging buffer, the streams — 150-180 ms of the 213 ms of a cold cornell frame (profiles/r03z_oneshot_trace.txt) — and, where a
+// big frame follows, the path arena, whose hipMalloc takes 0.4 ms on a device whose memory is clean and 0.2-1.4 s where the driver
+// has pages to clear (profiles/r04z_bench.json).  Round 4 did all of it in a static initialiser, so that merely loading the library
+// created a context and took 64 GiB on LOCAL_RANK's device.  Now LOADING THE LIBRARY MAKES NO HIP CALL: the host calls
+// fw_init(device, arena_bytes) where it wants the cost (the CLI and bench.py do, before their timed regions), and a host that never
+// does gets the same initialisation — without an arena — from its first fw_scene_create / fw_render on that device.
+// Caller holds ws->mu and has made `dev` current.
+int init_device_locked(Workspace *ws, int dev) {
+    if (ws->inited) return FW_OK;
+    if (device_cus(dev) <= 0) return fail(FW_ERR_HIP, "hipGetDeviceProperties failed");
+    if (!ws->staging) { HIPCHK(hipHostMalloc(&ws->staging, 1 << 20, hipHostMallocDefault)); ws->staging_bytes = 1 << 20; }
+    if (!ws->upload_stream) HIPCHK(hipStreamCreateWithFlags(&ws->upload_stream, hipStreamNonBlocking));
+    if (!ws->ev_upload) HIPCHK(hipEventCreateWithFlags(&ws->ev_upload, hipEventDisableTiming));
+    for (int l = 0; l < 2; l++) if (!ws->lanes[l].stream) HIPCHK(hipStreamCreateWithFlags(&ws->lanes[l].stream, hipStreamNonBlocking));
     void *tmp = nullptr;
-    if (hipMalloc(&tmp, 256) != hipSuccess) return;
+    HIPCHK(hipMalloc(&tmp, 256));
     std::memset(ws->staging, 0, 256);
     fw::launch_upload(ws->upload_stream, ws->staging, tmp, 256);          // any launch loads the code objects of the whole library on this device
     fw::preload_kernels();                                                // ... and every kernel's first launch resolves it: 60 ms of a first frame's enqueue (gpurun_out/r04j)
-    if (ws->ev_upload) (void)hipEventRecord(ws->ev_upload, ws->upload_stream);
-    (void)hipStreamSynchronize(ws->upload_stream);
-    (void)hipGetLastError();
+    (void)hipEventRecord(ws->ev_upload, ws->upload_stream);
+    const hipError_t e = hipStreamSynchronize(ws->upload_stream);
     (void)hipFree(tmp);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(FW_ERR_HIP, std::string("first launch failed: ") + hipGetErrorString(e)); }
+    (void)hipGetLastError();
+    ws->inited = true;
+    return FW_OK;
 }
-struct Preload {
-    Preload() {
-        if (getenv("FIREWORK_NO_PRELOAD")) return;
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return; }
-        int dev = 0;
-        if (const char *lr = getenv("LOCAL_RANK")) dev = atoi(lr);
-        if (dev < 0 || dev >= n) dev = 0;
-        warm_device(dev);
+// The arena grows by allocating the new one FIRST and freeing the old one on a background thread: hipFree of a 35 GB arena took 2.4 s of
+// the caller's time (gpurun_out/r04j/oneshot.txt) while the allocation itself is lazy.  Only when both do not fit is the old one freed
+// in line.  Caller holds ws->mu; no render of this workspace is in flight (fw_render returns after its stream has drained).
+int arena_reserve_locked(Workspace *ws, int dev, size_t want) {
+    if (want <= ws->arena.bytes && ws->arena.p) return FW_OK;
+    void *old_p = ws->arena.p;
+    void *np = nullptr;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess && old_p) {         // no room for both
+        (void)hipGetLastError();
+        (void)hipFree(old_p); old_p = nullptr; ws->arena.p = nullptr; ws->arena.bytes = 0;
+        e = hipMalloc(&np, want);
     }
-} g_preload;
+    if (e != hipSuccess) { (void)hipGetLastError(); ws->arena.p = old_p; if (!old_p) ws->arena.bytes = 0; return fail(FW_ERR_OOM, "path arena allocation failed: " + std::to_string(want >> 20) + " MiB"); }
+    ws->arena.p = np; ws->arena.bytes = want;
+    if (old_p) std::thread([old_p, dev] { if (hipSetDevice(dev) == hipSuccess) (void)hipFree(old_p); }).detach();
+    return FW_OK;
+}
+size_t default_arena_bytes(const Workspace *ws) {      // what fw_init(device, 0) reserves: every default-budget frame of the BASELINE configs fits (the largest needs 52 GB)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return std::min<size_t>((size_t)64 << 30, (free_b + ws->arena.bytes) / 3) & ~(((size_t)1 << 30) - 1);
+}
 
 } // namespace
 
@@ -1210,10 +1215,10 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     Workspace *ws = workspace_for(device);
     if (!ws) { delete sc; return fail(FW_ERR_OOM, "no workspace for this device"); }
     std::lock_guard<std::mutex> ws_guard(ws->mu);
+    if ((rc = init_device_locked(ws, device)) != FW_OK) { delete sc; return rc; }      // a host that never called fw_init pays for the device here, once
     // the blob is assembled in pinned host memory (grown on demand, kept per device) and copied by a kernel on the null
     // stream; renders of this scene wait for ws->ev_upload in stream order, the host never blocks here
-    if (ws->ev_upload) (void)hipEventSynchronize(ws->ev_upload);          // the previous upload has read the staging buffer (long done)
-    else if (hipEventCreateWithFlags(&ws->ev_upload, hipEventDisableTiming) != hipSuccess) { delete sc; return fail(FW_ERR_HIP, "hipEventCreate failed"); }
+    (void)hipEventSynchronize(ws->ev_upload);          // the previous upload has read the staging buffer (long done)
     if (ws->staging_bytes < total) {
         if (ws->staging) (void)hipHostFree(ws->staging);
         ws->staging = nullptr; ws->staging_bytes = 0;
@@ -1341,11 +1346,12 @@ fw::DCamera make_camera(const fw_camera_settings &s, uint32_t width, uint32_t he
 // (measured on cornell 512x512@1024: 4 Mi paths 85 ms/frame, 16 Mi 64 ms, 256 Mi = the whole frame 55 ms).
 // Default: up to 2^28 paths (104 B per slot + 40 B for parked mesh rays, and up to twice as many slots as paths because a
 // wave's queue capacity is a power of two: 28-77 GB), never more than half of the free HBM.
-uint32_t default_paths_per_batch(const Options &O) {
+uint32_t default_paths_per_batch(const Options &O, size_t arena_bytes) {
     if (O.paths_per_batch > 0) return (uint32_t)std::min<long long>(O.paths_per_batch, 0x7fffffffll);
     size_t free_b = 0, total_b = 0;
     uint64_t budget = 1ull << 28;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) budget = std::min<uint64_t>(budget, (uint64_t)(free_b / 2) / 288u);
+    // (the arena's own bytes count as available: the pools are carved out of it)
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + arena_bytes > 0) budget = std::min<uint64_t>(budget, (uint64_t)((free_b + arena_bytes) / 2) / 288u);
     return (uint32_t)std::max<uint64_t>(budget, 1u << 16);
 }
 
@@ -1368,6 +1374,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     Workspace *ws = workspace_for(sc->device);
     if (!ws) return fail(FW_ERR_OOM, "no workspace for this device");
     std::lock_guard<std::mutex> ws_guard(ws->mu);
+    { const int irc = init_device_locked(ws, sc->device); if (irc) return irc; }     // after fw_release_workspace, or a scene made before it
     const Options O = options();
 
     // ---- batches and lanes -----------------------------------------------------------------------------------
@@ -1384,7 +1391,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     int n_lanes = (p->use_bvh || sc->n_defer > 0) ? 2 : 1;
     if (O.streams >= 1) n_lanes = std::min(O.streams, (int)Workspace::MAX_LANES);
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, p->samples);
-    uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch(O) / (uint32_t)n_lanes;
+    uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch(O, ws->arena.bytes) / (uint32_t)n_lanes;
     uint32_t spp_b = std::max<uint32_t>(1u, budget / n_pix);
     spp_b = std::min(spp_b, (p->samples + (uint32_t)n_lanes - 1) / (uint32_t)n_lanes);     // at least one batch per lane
     uint64_t paths64 = (uint64_t)n_pix * spp_b;
@@ -1456,16 +1463,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     };
     {
         size_t want = (layout(nullptr) + ((size_t)1 << 30) - 1) & ~(((size_t)1 << 30) - 1);
-        if (want > ws->arena.bytes) {
-            // growing means hipFree + hipMalloc of tens of GB: 2.8 s for 35 -> 36 GiB (gpurun_out/r04j/oneshot.txt), while the allocation itself is
-            // lazy and costs 0.4 ms.  So the arena is made once, big enough for every default-budget frame (the largest config's pools are 52 GB),
-            // memory permitting, and grows only past that.
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) want = std::max(want, std::min<size_t>((size_t)64 << 30, (free_b + ws->arena.bytes) / 3));
-        }
+        // Round 5: the arena is sized by what is asked of it — fw_init(device, bytes) where the host reserved one, else this call's own
+        // layout — and grows by a quarter at least, the new allocation made first and the old one freed on a background thread
+        // (arena_reserve_locked): hipFree + hipMalloc in line cost 2.8 s for 35 -> 36 GiB (gpurun_out/r04j/oneshot.txt).
+        if (want > ws->arena.bytes && ws->arena.bytes) want = std::max(want, (ws->arena.bytes + ws->arena.bytes / 4 + ((size_t)1 << 30) - 1) & ~(((size_t)1 << 30) - 1));
         const auto ta = std::chrono::steady_clock::now();
         const bool grow = want > ws->arena.bytes;
-        need(ws->arena, want);
+        if (!rc && grow) rc = arena_reserve_locked(ws, sc->device, want);
         if (O.trace && grow) fprintf(stderr, "[firework] render: path arena grown to %.1f GiB in %.2f ms\n", (double)want / (double)(1 << 30),
                                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count());
         if (!rc) layout((uint8_t *)ws->arena.p);
@@ -1854,6 +1858,31 @@ int fw_selftest_wide_bvh(const float *boxes, uint32_t n, int format, uint32_t *v
 #if FW_AB
 int fw_debug_ab(void) { return 1; }      // present only in the A/B build: tests of the alternative kernels look for it
 #endif
+
+int fw_init(int device, uint64_t arena_bytes) {
+    try {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(FW_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)"); }
+        if (device < 0 || device >= ndev) return fail(FW_ERR_BAD_ARG, "device index out of range");
+        HIPCHK(hipSetDevice(device));
+        Workspace *ws = workspace_for(device);
+        if (!ws) return fail(FW_ERR_OOM, "no workspace for this device");
+        std::lock_guard<std::mutex> g(ws->mu);
+        int rc = init_device_locked(ws, device);
+        if (rc) return rc;
+        size_t want = arena_bytes == FW_INIT_NO_ARENA ? 0 : (arena_bytes ? (size_t)arena_bytes : default_arena_bytes(ws));
+        want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        if (want > ws->arena.bytes) {
+            const auto ta = std::chrono::steady_clock::now();
+            rc = arena_reserve_locked(ws, device, want);
+            if (options().trace) fprintf(stderr, "[firework] fw_init: path arena of %.1f GiB in %.2f ms\n", (double)want / (double)(1 << 30),
+                                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count());
+        }
+        return rc;
+    }
+    catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
+    catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_init"); }
+}
 
 int fw_scene_create(const fw_scene_desc *desc, int device, fw_scene **out) {
     try { return create_scene_impl(desc, device, out); }

@@ -103,6 +103,7 @@ class TiledRenderer:
         self.tg = TileGather(s["width"], s["height"], rank, world, self.dev, dist, tile, host_staged=host_staged_gather,
                              force_collective=force_collective)
         self.last_ms_gather = 0.0
+        _lib.init(device)          # fw_init on this rank's own device (idempotent): nothing of it lands in a rank's first frame
         self.scene = _lib.DeviceScene(scene if hasattr(scene, "ptr") else scene.to_desc(), device)
         self.world = world
         self.last_stats = None

@@ -209,6 +209,13 @@ class Lowered {
         shapes.push_back(fs); return (int32_t)shapes.size() - 1; }
 };
 
+// fw_init (ABI v7): the device's one-off costs — HIP context, code objects, kernel handles, the path arena — where the host wants them, i.e.
+// before the region it times (main.rs:40-44 starts with the reference's own binary loaded).  Optional: the first render does it otherwise.
+inline void init(int device = 0, uint64_t arena_bytes = 0) {
+    const int rc = fw_init(device, arena_bytes);
+    if (rc != FW_OK) throw std::runtime_error(std::string(fw_strerror(rc)) + " | " + fw_last_error());
+}
+
 struct Renderer {   // render.rs:59-218; Default: 1920x1080, 128 spp, multithreaded, no BVH, gamma 2.2
     size_t width_ = 1920, height_ = 1080, samples_ = 128; bool multithreaded_ = true, use_bvh_ = false; float gamma_ = 2.2f;
     CameraSettings camera_; uint64_t seed_ = 0; int device_ = 0;

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 6   /* 6: + fw_set_option (the runtime switches leave the environment: read once at load), fw_selftest_wide_bvh; 3: + fw_render_progressive; 4: fw_stats carries this layout's own HBM bytes per kernel class and the one-shot timings;
+#define FW_ABI_VERSION 7   /* 7: + fw_init (loading the library no longer touches the GPU); options EXACT_PRODUCT; 6: + fw_set_option (the runtime switches leave the environment: read once at load), fw_selftest_wide_bvh; 3: + fw_render_progressive; 4: fw_stats carries this layout's own HBM bytes per kernel class and the one-shot timings;
                               5: + fw_selftest_libm; the 4th float of an accumulation record counts the path segments of the samples that deposited */
 
 /* ---- status codes ------------------------------------------------------ */
@@ -237,6 +237,18 @@ int fw_abi_version(void);
 const char *fw_strerror(int status);
 const char *fw_last_error(void);            /* thread-local detail for the last failing call */
 int fw_device_count(void);                  /* number of visible HIP devices (0 if none) */
+
+/* Initialisation of one device, explicit and idempotent (ABI v7): the HIP context, this library's code objects and kernel
+   handles, its streams and pinned staging, and a path arena of `arena_bytes` (0 = the default: a third of the free HBM, at most
+   64 GiB — every default-budget frame of the BASELINE configs fits; FW_INIT_NO_ARENA = none, the first render sizes its own).
+   Loading the library makes NO HIP call and holds no memory; a host that never calls fw_init gets the same initialisation,
+   without an arena, from its first fw_scene_create / fw_render* on the device (SURVEY §8(b) "Ownership": a lazily created
+   per-device context is the only global state).  What it is for: the reference's timed region (main.rs:40-44) starts with
+   the process already loaded; a host that wants that region free of one-off costs (0.2-1.1 s for context, code objects
+   and, where the driver has pages to clear, the arena) calls fw_init first — `python -m firework_amd` and bench.py do.
+   Calling it again with a larger arena_bytes grows the arena; a smaller one changes nothing. */
+#define FW_INIT_NO_ARENA UINT64_MAX
+int fw_init(int device, uint64_t arena_bytes);
 
 /* `Scene -> SceneInternal` (scene.rs:111-135) + `build_bvh` (bvh.rs:79-85, mesh.rs:21-30):
    flatten, build TLAS/BLAS with the reference's median split, upload to `device`. */

@@ -55,10 +55,35 @@ class OracleError(RuntimeError):
         super().__init__(f"oracle error {status}: {load().fwo_strerror(status).decode()}")
 
 
-def render(scene, renderer, pixel_ids=None, rng_mode=A.FW_RNG_CTR, n_threads=0):
-    """Renderer::render on the CPU oracle.  `scene`: firework_amd.api.Scene or SceneDesc."""
+def native_timing_build():
+    """A second build of the SAME source with -O3 -march=native, made on the host it runs on, for bench.py's cpu_baseline leg ONLY — how fast
+    the restatement runs when the compiler may use the host's own instructions.  Never the checker: every comparison in tests/, smoke() and
+    bench.py's parity leg uses liboracle.so (-O2 -ffp-contract=off, oracle/Makefile).  -> path of the library, or None if it cannot be built."""
+    import hashlib
+    import subprocess
+    import tempfile
+    src = os.path.join(_HERE, "fw_oracle.cpp")
+    tag = hashlib.sha256(open(src, "rb").read()).hexdigest()[:12]
+    out = os.path.join(tempfile.gettempdir(), f"liboracle_native_{tag}_{os.getuid()}.so")
+    if not os.path.exists(out):
+        cmd = ["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-pthread", "-shared", "-o", out + ".tmp", src]
+        try:
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300)
+            os.replace(out + ".tmp", out)
+        except Exception:
+            return None
+    return out
+
+
+def render(scene, renderer, pixel_ids=None, rng_mode=A.FW_RNG_CTR, n_threads=0, timing_lib=None):
+    """Renderer::render on the CPU oracle.  `scene`: firework_amd.api.Scene or SceneDesc.
+    timing_lib: path of native_timing_build()'s library (bench.py's cpu_baseline leg only: timed, never compared)."""
     from firework_amd.api import RenderResult, SceneDesc
     lib = load()
+    if timing_lib:
+        lib = C.CDLL(timing_lib)
+        lib.fwo_render.restype = C.c_int
+        lib.fwo_render.argtypes = [C.POINTER(A.fw_scene_desc), C.POINTER(A.fw_render_params), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(A.fw_stats)]
     sd = scene if isinstance(scene, SceneDesc) else scene.to_desc()
     ids = None if pixel_ids is None else np.ascontiguousarray(np.asarray(pixel_ids, dtype=np.uint32))
     p = renderer.to_params(ids, rng_mode)

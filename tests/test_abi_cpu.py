@@ -61,3 +61,42 @@ def test_product_never_references_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in text and "oracle_binding" not in text and "fwo_" not in text, f
+
+
+_SHIM = r"""
+#include <stdio.h>
+#include <stdlib.h>
+static void note(const char *n) { const char *f = getenv("FW_SHIM_LOG"); if (f) { FILE *p = fopen(f, "a"); if (p) { fprintf(p, "%s\n", n); fclose(p); } } }
+#define TRAP(name) int name() { note(#name); return 100; }
+TRAP(hipInit) TRAP(hipGetDeviceCount) TRAP(hipSetDevice) TRAP(hipGetDevice) TRAP(hipMalloc) TRAP(hipHostMalloc) TRAP(hipMemGetInfo)
+TRAP(hipStreamCreateWithFlags) TRAP(hipEventCreateWithFlags) TRAP(hipGetDevicePropertiesR0600) TRAP(hipGetDeviceProperties)
+TRAP(hipLaunchKernel) TRAP(hipFuncGetAttributes) TRAP(hipMemcpy) TRAP(hipMemcpyAsync) TRAP(hipDeviceSynchronize)
+"""
+
+
+def test_loading_the_library_makes_no_hip_call(tmp_path):
+    """ABI v7 / SURVEY §8(b) "Ownership": dlopen alone creates no context, queries no device and allocates nothing — the first HIP call
+    is made by fw_init or by the first call that needs the device.  A preloaded shim traps the runtime's entry points."""
+    import subprocess
+    import sys
+    (tmp_path / "shim.c").write_text(_SHIM)
+    shim = str(tmp_path / "shim.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-w", "-o", shim, str(tmp_path / "shim.c")])
+    log = tmp_path / "calls.txt"
+    code = ("import ctypes, os; lib = ctypes.CDLL(os.environ['FW_LIB_PATH']); print('loaded', lib.fw_abi_version());"
+            "open(os.environ['FW_SHIM_LOG'], 'a').write('-- after load\\n'); lib.fw_init.argtypes = [ctypes.c_int, ctypes.c_uint64]; print('init', lib.fw_init(0, 0))")
+    env = dict(os.environ, LD_PRELOAD=shim, FW_SHIM_LOG=str(log), FW_LIB_PATH=_lib.LIB_PATH, LOCAL_RANK="0")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, text=True)
+    assert "loaded %d" % A.FW_ABI_VERSION in out
+    before, after = log.read_text().split("-- after load\n")
+    assert before == "", "HIP calls during dlopen: " + before
+    assert "hipGetDeviceCount" in after          # ... and fw_init is where the runtime is first asked for a device
+
+
+def test_fw_init_without_a_device_fails_loudly():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    lib = _lib.load()
+    assert lib.fw_init(0, 0) == A.FW_ERR_NO_DEVICE
+    with pytest.raises(_lib.FireworkError):
+        _lib.init()
