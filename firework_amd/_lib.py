@@ -69,6 +69,8 @@ def load(preload=False, device=None):
     lib.fw_set_option.argtypes = [C.c_char_p, C.c_char_p]
     lib.fw_selftest_wide_bvh.restype = C.c_int
     lib.fw_selftest_wide_bvh.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.fw_selftest_bvh_build.restype = C.c_int
+    lib.fw_selftest_bvh_build.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     lib.fw_init.restype = C.c_int
     lib.fw_init.argtypes = [C.c_int, C.c_uint64]
     if lib.fw_abi_version() != A.FW_ABI_VERSION:
@@ -132,6 +134,16 @@ def selftest_wide_bvh(boxes, fmt):
     stats = (C.c_uint32 * 4)()
     _check(lib, lib.fw_selftest_wide_bvh(b.ctypes.data, b.shape[0], int(fmt), C.byref(bad), stats))
     return int(bad.value), dict(nodes=int(stats[0]), leaves=int(stats[1]), free_slots=int(stats[2]), depth=int(stats[3]))
+
+
+def selftest_bvh_build(boxes, threads):
+    """fw_selftest_bvh_build (CPU only): the host tree builders with `threads` threads.  -> (hash of the median tree, hash of the SAH tree, stats)"""
+    lib = load()
+    b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 6)
+    h = (C.c_uint64 * 2)()
+    st = (C.c_uint32 * 4)()
+    _check(lib, lib.fw_selftest_bvh_build(b.ctypes.data, b.shape[0], int(threads), h, st))
+    return int(h[0]), int(h[1]), dict(median_nodes=int(st[0]), median_depth=int(st[1]), sah_nodes=int(st[2]), sah_depth=int(st[3]))
 
 
 def selftest_arith(n, seed=1, mode=0, device=0):

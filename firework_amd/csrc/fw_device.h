@@ -175,6 +175,8 @@ struct DFrame {
     float cam_pos[3];
     uint32_t chain_bits;          // != 0: 8-byte path state (fw_kernels.hip: load_state_chain): bits per material id in the chain; every material's
                                   // attenuation is a constant of the material and 10 ids fit 32 bits (host: fw_scene.chain_bits)
+    float4 *atten;                // option EXACT_PRODUCT (scenes without a chain state, i.e. with a varying texture): the attenuation of every scattering, [segment][home
+    uint32_t atten_stride;        // slot] (stride = slots per segment); a path that ends in light multiplies them back to front like the reference's recursion.  nullptr: off
     DExact ex;                    // which rays are traced a second time by the literal reference walk
 };
 
@@ -206,7 +208,7 @@ struct DPark {
 
 // Bytes per record of the streams above: what fw_stats.bytes_* (the layout's own algorithmic HBM bytes) are computed from,
 // kept next to the layout so that the two change together.
-constexpr uint32_t B_RAY = 24, B_RAY_PINHOLE0 = 16, B_STATE = 16, B_STATE_CHAIN = 8, B_HIT = 8, B_HIT4 = 4, B_DEPOSIT = 16, B_PARK = 40, B_ACCUM = 16;
+constexpr uint32_t B_RAY = 24, B_RAY_PINHOLE0 = 16, B_STATE = 16, B_STATE_CHAIN = 8, B_HIT = 8, B_HIT4 = 4, B_DEPOSIT = 16, B_PARK = 40, B_ACCUM = 16, B_ATTEN = 16;
 
 constexpr uint32_t MISS = 0xffffffffu;
 constexpr int MAX_SEGMENTS = 11;
@@ -231,6 +233,7 @@ struct LaunchCfg {
     uint32_t ref_tlas_nodes, ref_blas_nodes, ref_tlas_depth, ref_blas_depth;   // the reference trees k_extend_exact walks (nodes of 32 B)
     int wblas_fmt, wtlas_fmt;     // WIDE_NONE / WIDE_F32 / WIDE_Q8: the encoding of DScene.wblas / wtlas (FIREWORK_WIDE=0: none; =q8 / =f32 force one)
     uint32_t wblas_nodes, wtlas_nodes, wblas_depth, wtlas_depth;   // wide nodes; wide nodes on the longest root-to-leaf path
+    uint32_t debug_wide_levels;   // A/B build, option DEBUG_WIDE_LEVELS: LDS stack levels of the wide walks instead of 3 * depth + 2 (the error word's test); 0: off
     bool tlas_refill;     // refilling walks: k_extend_tlas (no meshes) / k_extend_tlas_park + k_blas (meshes); FIREWORK_TLAS_REFILL=0: the chunked k_extend_bvh
 };
 constexpr size_t LDS_TREE_LIMIT = 160 * 1024;   // the whole LDS of a CU: one workgroup of the LDS-resident walks per CU
@@ -248,6 +251,9 @@ void launch_scatter_tiles(hipStream_t stream, const uint32_t *ids, uint32_t n, c
                           uint8_t *out8, float *outg, float *outl);
 void launch_tile_order(hipStream_t stream, uint32_t width, uint32_t height, uint32_t *ids);
 void launch_upload(hipStream_t stream, const void *pinned_src, void *dst, size_t bytes);
+#if FW_AB
+uint32_t take_error_word();   // the device's error word (fw_kernels.hip: g_err_word), read and cleared
+#endif
 void preload_kernels();    // resolves every kernel of the default paths on the current device (a first launch pays ~2 ms for it otherwise)
 void launch_count_deposits(const LaunchCfg &, const uint32_t *dep_bits, uint32_t *total);
 void launch_selftest_arith(hipStream_t stream, uint32_t n, uint32_t seed, int mode, unsigned long long *out);

@@ -205,7 +205,11 @@ __device__ __forceinline__ RngKey key_of_linear(const DFrame &f, uint32_t linear
     if (p_local < 0) { s_local--; p_local += (int32_t)f.n_pixels; }
     else if ((uint32_t)p_local >= f.n_pixels) { s_local++; p_local -= (int32_t)f.n_pixels; }
     RngKey k;
+#ifdef FW_ABL_NO_PIXGATHER      // timing ablation (wrong frames): no lookup of the pixel id
+    k.pixel = (uint32_t)p_local;
+#else
     k.pixel = f.pixel_ids ? f.pixel_ids[p_local] : (uint32_t)p_local;
+#endif
     k.sample = f.sample0 + s_local;
     k.seed32 = f.seed32;
     return k;
@@ -391,7 +395,19 @@ __shared__ float g_ts[8 * 64];
 #define TS_END() do { } while (0)
 #endif
 
-__device__ __forceinline__ uint32_t wave_index() { return blockIdx.x * (WB / 64) + (threadIdx.x >> 6); }
+#ifndef FW_XCD_SWIZZLE
+#define FW_XCD_SWIZZLE 0
+#endif
+// Which queue a single-wave workgroup takes.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b mod 8), so with w = b the
+// waves resident on one XCD own every 8th queue; FW_XCD_SWIZZLE=1 gives XCD x the contiguous eighth [x n/8, (x+1) n/8) instead (timing
+// experiment, round 5: neighbouring windows of the path arrays per XCD, for its L2 TLB).  Any bijection is correct: queues are private.
+__device__ __forceinline__ uint32_t wave_index() {
+#if FW_XCD_SWIZZLE
+    const uint32_t per = gridDim.x >> 3;
+    if ((gridDim.x & 7u) == 0u) return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+#endif
+    return blockIdx.x * (WB / 64) + (threadIdx.x >> 6);
+}
 
 // Hit record: 8 bytes (t, code) with code = object << prim_bits | primitive (rect3d face / mesh triangle), MISS = all
 // ones.  k_shade is HBM-bound (88 % of what its streams can reach), so bytes are what it pays for.
@@ -2211,9 +2227,29 @@ __global__ __launch_bounds__(LDS_WAVES * 64) void k_extend_tlas_lds(DScene sc, D
 // 6 subtractions, 6 multiplications, max3 / min3 and two comparisons.  The children that pass are ordered by a 5-comparator
 // network on 32-bit keys (upper half of the entry distance | reference): nearest next, the others pushed farthest first.
 // ------------------------------------------------------------------------------------------------
+// The device's ERROR WORD (A/B build, -DFW_AB=1: the build experiments are made in).  A walk kernel that would write past its LDS stack, or
+// whose wave stops making progress, sets a bit here instead, drops the push / leaves its loop, and the render returns FW_ERR_HIP with the bit
+// named in fw_last_error() — a fault or a hang inside a kernel cannot be turned into a status code after the fact: the runtime aborts the
+// process (round 4's r04t: DESIGN.md §6).  The product build carries no check: its stack sizes are derived from the tree's depth on the
+// host (3 * depth + 2 levels: at most three pushes per wide node on the path) and its loops retire a ray or consume one every round.
+#if FW_AB
+__device__ uint32_t g_err_word;
+enum : uint32_t { ERR_STACK_OVERFLOW = 1u, ERR_NO_PROGRESS = 2u };
+constexpr uint32_t WATCHDOG_ROUNDS = 1u << 24;     // rounds of one wave's walk loop; a wave handles a few thousand rays in a few rounds each
+#define FW_WATCHDOG_DECL uint32_t watchdog_ = 0
+#define FW_WATCHDOG_TICK if (++watchdog_ > WATCHDOG_ROUNDS) { if ((threadIdx.x & 63u) == 0) atomicOr(&g_err_word, ERR_NO_PROGRESS); break; }
+#else
+#define FW_WATCHDOG_DECL do { } while (0)
+#define FW_WATCHDOG_TICK do { } while (0)
+#endif
 struct LdsStackW {   // 16-bit references, [level][lane] over the 64 lanes of one wave
     uint16_t *s; int sp;
+#if FW_AB
+    int cap;         // levels this stack owns: a push beyond them is dropped and flagged (the walk then misses a subtree: the frame is wrong, the call fails)
+    __device__ __forceinline__ void push(uint32_t v) { if (sp >= cap) { atomicOr(&g_err_word, ERR_STACK_OVERFLOW); return; } s[sp * 64] = (uint16_t)v; sp++; }
+#else
     __device__ __forceinline__ void push(uint32_t v) { s[sp * 64] = (uint16_t)v; sp++; }
+#endif
     __device__ __forceinline__ uint32_t pop() { sp--; return s[sp * 64]; }
 };
 // per ray: WIDE_F32 byte offsets (inside a node) of the near planes of x, y, z (the far planes lie at 48 - q[0], 80 - q[1], 112 - q[2]); WIDE_Q8: q[0..2] = inv < 0
@@ -2316,7 +2352,12 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
     bool soft = false;
     WideSel sel = wide_sel<FMT>(inv);
     TriRay tr{mk(0, 0, 0), 0, 1, 2, 0.f, 0.f, 0.f};
+#if FW_AB
+    LdsStackW st{stacks + (size_t)wib * levels * 64u + lane, 0, (int)levels};
+#else
     LdsStackW st{stacks + (size_t)wib * levels * 64u + lane, 0};
+#endif
+    FW_WATCHDOG_DECL;
     PH_DECL;
     uint32_t more = 0, pidx = 0;            // the meshes this ray still has to walk after the current one (park_next_mesh), and where its parked entry lies
     auto start_walk = [&](uint32_t mesh_obj, float4 ra, float2 rb) {
@@ -2331,6 +2372,7 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
         have = false; mbest = TMAX; mtri = 0; act = true;
     };
     for (;;) {
+        FW_WATCHDOG_TICK;
         const unsigned long long idle_mask = __ballot(!act);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
         if (c_pos < c_n) {
@@ -2467,9 +2509,15 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene
     float best_t = TMAX; bool have = false;
     V3 wo = mk(0, 0, 0), wd = wo, inv = wo;
     WideSel sel = wide_sel<WIDE_F32>(inv);
+#if FW_AB
+    LdsStackW st{stacks + (size_t)wib * levels * 64u + lane, 0, (int)levels};
+#else
     LdsStackW st{stacks + (size_t)wib * levels * 64u + lane, 0};
+#endif
+    FW_WATCHDOG_DECL;
     PH_DECL;
     for (;;) {
+        FW_WATCHDOG_TICK;
         const unsigned long long idle_mask = __ballot(slot == IDLE);
         const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
         if (c_pos < c_n) {
@@ -2950,6 +2998,13 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
     // what the path carries to the camera of a radiance x found at this segment: beta * x, or with the chain the reference's own
     // nesting a0 * (a1 * (... (a_{k-1} * x))) (render.rs:23-28: `emit + attenuation * color(..)`, emit = 0 on the way)
     auto carried = [&](V3 x) -> V3 {
+        if (!CHAIN && f.atten) {        // option EXACT_PRODUCT: the attenuations themselves, one record per scattering at the path's home slot
+            for (int sgm = segment - 1; sgm >= 0; sgm--) {
+                const float4 c = f.atten[(size_t)sgm * f.atten_stride + path_id];
+                x = mk(c.x, c.y, c.z) * x;
+            }
+            return x;
+        }
         if (!CHAIN) return beta * x;
         const uint32_t mask = (1u << f.chain_bits) - 1u;
         for (int sgm = segment - 1; sgm >= 0; sgm--) {
@@ -3023,13 +3078,20 @@ __device__ __forceinline__ bool shade_path(const DScene &sc, const DFrame &f, co
             default: break;
             }
             if (CHAIN) nchain = chain | (o.material << (f.chain_bits * (uint32_t)segment));   // atten IS the material's constant (host: chain_bits)
-            else nbeta = beta * atten;
+            else {
+                nbeta = beta * atten;
+                if (f.atten && alive) f.atten[(size_t)segment * f.atten_stride + path_id] = make_float4(atten.x, atten.y, atten.z, 0.f);
+            }
             PH_ADD(5);
         }
     }
     // every path deposits exactly once — except zeros over a black environment: k_raygen has already written them, densely
     // (adding +0 is exact, and most indoor paths end black; the scattered 16-byte deposits are k_shade's costliest stores)
+#ifdef FW_ABL_NO_DEPOSIT      // timing ablation (wrong frames): no radiance record, no bit
+    if (false) {
+#else
     if (!alive && !(f.skip_zero_deposits && rad.x == 0.f && rad.y == 0.f && rad.z == 0.f)) {
+#endif
         PH_T0;
         // .w = the path's length in segments: k_accumulate sums it next to the colour, so accum.w of a pixel is its ray count
         // whenever every path deposits (any non-black environment, or FIREWORK_NO_ZERO_SKIP=1) — what tools/diverge.py
@@ -3108,7 +3170,11 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
         // acknowledgement of its own stores (54 % of k_shade's wave time in s_waitcnt, profiles/r04z_c2_sq.json).  With a static store count
         // the wait is vmcnt(3): the loads, nothing younger.
         if (c0 != 0xffffffffu) {
+#if FW_SHADE_STATIC_STORES == 2     // timing variant: every dead lane into ONE slot (the window's last: no survivor takes it while any lane died) — the waits without the traffic
+            const uint32_t dst = base + (alive ? out_n + rank : q.cap - 1u);
+#else
             const uint32_t dst = base + (alive ? out_n + rank : min(c0 + 64u + lane, q.cap - 1u));
+#endif
             qst(&out.ray_a[dst], make_float4(nr.o.x, nr.o.y, nr.o.z, nr.d.x));
             qst(&out.ray_b[dst], make_float2(nr.d.y, nr.d.z));
             if (CHAIN) qst(&reinterpret_cast<float2 *>(out.state)[dst], make_float2(__uint_as_float(nchain), __uint_as_float(path_id)));
@@ -3201,8 +3267,12 @@ __global__ __launch_bounds__(WB) void k_shade(DScene sc, DFrame f, DPaths in, DP
             V3 beta = mk(st.x, st.y, st.z);
             path_id = __float_as_uint(st.w);
             const uint32_t hit_code = __float_as_uint(hr.y);
+#ifdef FW_ABL_SHADE_COPY     // timing ablation (wrong frames): the queue streams and the compaction alone — every hit path survives unchanged
+            alive = hit_code != MISS && segment < 10; nr = r; nbeta = beta; nchain = __float_as_uint(st.x) + (pre_key ? pre_key->pixel & 1u : 0u);
+#else
             if (MODE == 2 && expensive_shading(sc, objp, matp, hit_code)) later = true;
             else alive = shade_path<MODE != 0, CHAIN>(sc, f, objp, matp, texp, r, beta, __float_as_uint(st.x), path_id, hr.x, hit_code, segment, sample_rad, nr, nbeta, nchain PH_PASS, pre_key);
+#endif
             PH_ADD(0);
         }
         { PH_T0; compact(alive, nr, nbeta, nchain, path_id, c0); PH_ADD(7); }
@@ -3589,7 +3659,7 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
         // The parked rays' BLAS walks.  WIDE nodes out of LDS where the scene has them (f32, or quantised for a BLAS too big for those):
         // as many waves per workgroup (16, 12, 8) as fit next to the tree, the triangles too when 16 waves still fit with them.
         if (c.lds_trees && c.wblas_fmt != WIDE_NONE && sc.wblas && c.max_tris < 0x7fffu) {
-            const uint32_t wl = 3u * c.wblas_depth + 2u;
+            const uint32_t wl = c.debug_wide_levels ? c.debug_wide_levels : 3u * c.wblas_depth + 2u;
             const size_t tree = (size_t)c.wblas_nodes * (c.wblas_fmt == WIDE_F32 ? WIDE_F32_DW : WIDE_Q8_DW) * 4, tris = (size_t)c.n_tris * 48;
             uint32_t waves = 0; bool lds_tris = false;
             if (!c.no_lds_tris && lds_walk_bytes(tree + tris, 16, wl, c.q.n_waves, walk_grid(16)) <= LDS_TREE_LIMIT) { waves = 16; lds_tris = true; }
@@ -3629,7 +3699,7 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     else if (use_bvh && c.tlas_refill) {
         // scenes without meshes: the whole TLAS in LDS when it fits next to the walks' stacks — WIDE nodes where the scene has them
         if (c.lds_trees && !c.has_mesh && sc.n_objects > TLAS_SCAN_MAX && c.wtlas_fmt == WIDE_F32 && sc.wtlas && sc.n_objects < 0x7fffu) {
-            const uint32_t wl = 3u * c.wtlas_depth + 2u;
+            const uint32_t wl = c.debug_wide_levels ? c.debug_wide_levels : 3u * c.wtlas_depth + 2u;
             const size_t tree = (size_t)c.wtlas_nodes * WIDE_F32_DW * 4;
             uint32_t waves = 0;
             for (uint32_t w : {16u, 12u, 8u}) if (lds_walk_bytes(tree, w, wl, c.q.n_waves, walk_grid(w)) <= LDS_TREE_LIMIT) { waves = w; break; }
@@ -3723,6 +3793,14 @@ void preload_kernels() {
 #undef FW_TOUCH
     (void)hipGetLastError();
 }
+#if FW_AB
+uint32_t take_error_word() {      // reads and clears the device's error word (after a frame's stream has drained); 0: none
+    uint32_t v = 0, zero = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_err_word), 4) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_err_word), &zero, 4);
+    return v;
+}
+#endif
 #ifdef FW_PHASE_STATS
 extern "C" int fw_debug_phase_stats(unsigned long long *out, int n) {   // debug builds only; reads and clears the sections' counters (3 per section)
     static unsigned long long zero[2 * 3 * PH_N];

@@ -11,6 +11,8 @@
 #include "fw_device.h"
 
 #include <algorithm>
+#include <atomic>
+#include <exception>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -37,7 +39,8 @@ struct Options {
     bool no_exact = false, exact_all = false;   // NO_EXACT: no literal walk at all; EXACT_ALL=1: every ray takes it (the renderer then IS bvh.rs:115-151)
     int exact_form = 0;           // EXACT_FORM=lane|wave
     bool no_defer = false, no_hit4 = false, no_hoist = false, no_lds_tables = false, no_lds_trees = false, no_lds_tris = false, no_short_rays = false,
-         no_tile_order = false, no_zero_skip = false, dep_pixel_major = false, dep_slot_major = false, trace = false, no_chain = false;
+         no_tile_order = false, no_zero_skip = false, dep_pixel_major = false, dep_slot_major = false, trace = false, no_chain = false,
+         exact_product = false;   // EXACT_PRODUCT: textured scenes keep every scattering's attenuation and multiply back to front at deposit (render.rs:23-28's order)
     int streams = 0;              // STREAMS=n batches in flight (0: the library's choice)
     int soft_shear_log2 = 5, exact_shear_log2 = 10; double exact_far_x = 256.0;   // SOFT_SHEAR_LOG2 (0: off), EXACT_SHEAR_LOG2, EXACT_FAR_X: the flag rules' thresholds (tools/flag_margin.py)
     double wide_node_cost = 0.0005;   // WIDE_NODE_COST: the constant a wide node costs in the collapse, in root areas (wide_convert)
@@ -47,13 +50,14 @@ struct Options {
     std::string dump_path;        // DUMP_PATH=file (tools/diverge.py)
 #if FW_AB
     bool fused = false, tlas_refill_off = false, shade_list = false, no_shade_defer = false, stagger = false;
+    int debug_wide_levels = 0;    // DEBUG_WIDE_LEVELS=n: undersized LDS stacks for the wide walks (the error word's test)
 #endif
 };
 const char *const OPTION_NAMES[] = {"BVH", "NO_EXACT", "EXACT_ALL", "EXACT_FORM", "NO_DEFER", "NO_HIT4", "NO_HOIST", "NO_LDS_TABLES", "NO_LDS_TREES", "NO_LDS_TRIS",
-                                    "NO_SHORT_RAYS", "NO_TILE_ORDER", "NO_ZERO_SKIP", "DEP_PIXEL_MAJOR", "DEP_SLOT_MAJOR", "NO_CHAIN", "SOFT_SHEAR_LOG2", "EXACT_SHEAR_LOG2", "EXACT_FAR_X", "WIDE_NODE_COST", "TRACE", "STREAMS", "WIDE", "WAVES",
+                                    "NO_SHORT_RAYS", "NO_TILE_ORDER", "NO_ZERO_SKIP", "DEP_PIXEL_MAJOR", "DEP_SLOT_MAJOR", "NO_CHAIN", "EXACT_PRODUCT", "SOFT_SHEAR_LOG2", "EXACT_SHEAR_LOG2", "EXACT_FAR_X", "WIDE_NODE_COST", "TRACE", "STREAMS", "WIDE", "WAVES",
                                     "PATHS_PER_BATCH", "DUMP_PATH",
 #if FW_AB
-                                    "FUSED", "TLAS_REFILL", "SHADE_LIST", "NO_SHADE_DEFER", "STAGGER",
+                                    "FUSED", "TLAS_REFILL", "SHADE_LIST", "NO_SHADE_DEFER", "STAGGER", "DEBUG_WIDE_LEVELS",
 #endif
                                     nullptr};
 bool option_apply(Options &o, const char *name, const char *v) {      // v == nullptr: back to the default
@@ -76,6 +80,7 @@ bool option_apply(Options &o, const char *name, const char *v) {      // v == nu
     else if (n == "DEP_PIXEL_MAJOR") o.dep_pixel_major = on();
     else if (n == "DEP_SLOT_MAJOR") o.dep_slot_major = on();
     else if (n == "NO_CHAIN") o.no_chain = on();
+    else if (n == "EXACT_PRODUCT") o.exact_product = v && atoi(v) != 0;
     else if (n == "SOFT_SHEAR_LOG2") o.soft_shear_log2 = v ? (int)num() : 5;
     else if (n == "EXACT_SHEAR_LOG2") o.exact_shear_log2 = v ? (int)num() : 10;
     else if (n == "EXACT_FAR_X") o.exact_far_x = v ? atof(v) : 256.0;
@@ -92,6 +97,7 @@ bool option_apply(Options &o, const char *name, const char *v) {      // v == nu
     else if (n == "SHADE_LIST") o.shade_list = on();
     else if (n == "NO_SHADE_DEFER") o.no_shade_defer = on();
     else if (n == "STAGGER") o.stagger = on();
+    else if (n == "DEBUG_WIDE_LEVELS") o.debug_wide_levels = (int)std::max<long long>(0, num());
 #endif
     else return false;
     return true;
@@ -158,11 +164,101 @@ struct FlatBvh {
 };
 struct NanError {};
 
-uint32_t bvh_build_rec(FlatBvh &out, const std::vector<Box> &boxes, uint32_t *idx, size_t n, uint32_t depth, Box &node_box) {
+// ---- parallel host builds (round 5).  The reference builds its trees inside its timed region (main.rs:40-44) on one thread; so did this
+// library until round 4: 1.0 s for the median tree and 0.5 s for the SAH tree of a million triangles (profiles/r05_big_mesh.txt).  Both
+// recursions are independent below a node, so a node with enough items hands its left subtree to another thread, which builds it into a
+// tree of its own; the two are appended behind the node in depth-first order (child indices shifted) — the same nodes in the same order as
+// the sequential build — and the big sorts and binning passes near the root are split over the threads that are still free.  A stable
+// sort's result does not depend on how it was computed, box unions (fmin / fmax) and counts are exact: the trees are bit-identical.
+struct BuildPool {
+    std::atomic<int> free_threads;
+    explicit BuildPool(int n) : free_threads(n) {}
+    int take(int want) {      // up to `want` helper threads (possibly 0)
+        int got = 0;
+        while (got < want) { int f = free_threads.load(); if (f <= 0) break; if (free_threads.compare_exchange_weak(f, f - 1)) got++; }
+        return got;
+    }
+    void give(int n) { free_threads.fetch_add(n); }
+};
+inline int host_build_threads() {
+    static const int n = [] { const char *e = getenv("FIREWORK_BUILD_THREADS"); int v = e ? atoi(e) : (int)std::thread::hardware_concurrency(); return std::max(1, std::min(v, 64)); }();
+    return n;
+}
+constexpr size_t PAR_SUBTREE_MIN = 4096, PAR_PASS_MIN = 1 << 15;     // items below which a subtree / a pass over the items stays on its thread
+
+// f(begin, end, part) over [0, n) in `parts` contiguous parts, part 0 on the calling thread
+template <class F> void par_parts(size_t n, int parts, F f) {
+    if (parts <= 1) { f((size_t)0, n, 0); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)parts - 1);
+    for (int k = 1; k < parts; k++) th.emplace_back([&, k] { f(n * (size_t)k / (size_t)parts, n * (size_t)(k + 1) / (size_t)parts, k); });
+    f((size_t)0, n / (size_t)parts, 0);
+    for (auto &t : th) t.join();
+}
+// std::stable_sort's result by any route: sorted parts, merged pairwise (inplace_merge is stable)
+template <class Cmp> void par_stable_sort(uint32_t *b, size_t n, Cmp cmp, BuildPool &pool) {
+    int helpers = n >= PAR_PASS_MIN ? pool.take(15) : 0;
+    int parts = 1; while (parts * 2 <= helpers + 1) parts *= 2;           // a power of two
+    pool.give(helpers - (parts - 1)); helpers = parts - 1;
+    if (parts == 1) { std::stable_sort(b, b + n, cmp); return; }
+    auto cut = [&](int k) { return n * (size_t)k / (size_t)parts; };
+    par_parts(n, parts, [&](size_t lo, size_t hi, int) { std::stable_sort(b + lo, b + hi, cmp); });
+    for (int width = 1; width < parts; width *= 2) {
+        const int pairs = parts / (2 * width);
+        par_parts((size_t)pairs, pairs, [&](size_t lo, size_t hi, int) {
+            for (size_t q = lo; q < hi; q++) std::inplace_merge(b + cut((int)q * 2 * width), b + cut((int)q * 2 * width + width), b + cut((int)(q + 1) * 2 * width), cmp);
+        });
+    }
+    pool.give(helpers);
+}
+// appends tree `t` (root at its node 0) to `out`, child indices shifted; returns where its root went
+inline uint32_t append_tree(FlatBvh &out, const FlatBvh &t) {
+    const uint32_t off = out.count();
+    out.nodes.insert(out.nodes.end(), t.nodes.begin(), t.nodes.end());
+    for (uint32_t i = 0; i < t.count(); i++) {
+        float *p = &out.nodes[(size_t)(off + i) * 8];
+        uint32_t A; std::memcpy(&A, p + 3, 4);
+        if ((A >> 30) == 0u) { A += off; std::memcpy(p + 3, &A, 4); }      // a Branch: its right child
+    }
+    out.depth = std::max(out.depth, t.depth);
+    return off;
+}
+// build(left, into) and build(right, into): the left one on a helper thread into a tree of its own when the node is big enough and a thread is
+// free, else both in place.  Returns the right child's index; lb / rb = the children's boxes.
+template <class Build> uint32_t build_children(FlatBvh &out, size_t n, size_t half, BuildPool &pool, Build build, Box &lb, Box &rb) {
+    if (n >= PAR_SUBTREE_MIN && pool.take(1) == 1) {
+        FlatBvh L, R;
+        std::exception_ptr ep;
+        std::thread th([&] { try { build(L, (size_t)0, half, lb); } catch (...) { ep = std::current_exception(); } });
+        try { build(R, half, n - half, rb); } catch (...) { th.join(); pool.give(1); throw; }
+        th.join(); pool.give(1);
+        if (ep) std::rethrow_exception(ep);
+        append_tree(out, L);
+        return append_tree(out, R);
+    }
+    build(out, (size_t)0, half, lb);                                    // left child = me + 1
+    const uint32_t before = out.count();
+    build(out, half, n - half, rb);
+    return before;
+}
+
+struct Centers { std::vector<float> c[3]; };     // box_center per item and axis, computed once per build (the comparators read them millions of times)
+inline Centers centers_of(const std::vector<Box> &boxes, BuildPool &pool) {
+    Centers ce;
+    const size_t n = boxes.size();
+    for (int a = 0; a < 3; a++) ce.c[a].resize(n);
+    const int helpers = n >= PAR_PASS_MIN ? pool.take(7) : 0;
+    par_parts(n, helpers + 1, [&](size_t lo, size_t hi, int) { for (size_t i = lo; i < hi; i++) { const V3 c = box_center(boxes[i]); ce.c[0][i] = c.x; ce.c[1][i] = c.y; ce.c[2][i] = c.z; } });
+    pool.give(helpers);
+    return ce;
+}
+
+uint32_t bvh_build_rec(FlatBvh &out, const std::vector<Box> &boxes, const Centers &ce, uint32_t *idx, size_t n, uint32_t depth, Box &node_box, BuildPool &pool) {
     int axis = (int)(depth % 3);
-    for (size_t i = 0; i < n; i++) { float c = box_center(boxes[idx[i]])[axis]; if (c != c) throw NanError(); }
+    const float *key = ce.c[axis].data();
+    for (size_t i = 0; i < n; i++) { float c = key[idx[i]]; if (c != c) throw NanError(); }
     // Rust's sort_by is stable; the sub-slice is re-sorted at every level (bvh.rs:29-35)
-    std::stable_sort(idx, idx + n, [&](uint32_t a, uint32_t b) { return box_center(boxes[a])[axis] < box_center(boxes[b])[axis]; });
+    par_stable_sort(idx, n, [key](uint32_t a, uint32_t b) { return key[a] < key[b]; }, pool);
     uint32_t me = out.count();
     out.nodes.resize(out.nodes.size() + 8);
     out.depth = std::max(out.depth, depth);
@@ -172,8 +268,8 @@ uint32_t bvh_build_rec(FlatBvh &out, const std::vector<Box> &boxes, uint32_t *id
     else {
         size_t half = n / 2;
         Box lb, rb;
-        bvh_build_rec(out, boxes, idx, half, depth + 1, lb);            // left child = me + 1
-        uint32_t right = bvh_build_rec(out, boxes, idx + half, n - half, depth + 1, rb);
+        const uint32_t right = build_children(out, n, half, pool, [&](FlatBvh &into, size_t first, size_t count, Box &b) {
+            bvh_build_rec(into, boxes, ce, idx + first, count, depth + 1, b, pool); }, lb, rb);
         node_box = box_union(lb, rb);
         A = right;
         B = (uint32_t)axis;     // split axis of this Branch (depth % 3): picks the near child during traversal
@@ -183,11 +279,14 @@ uint32_t bvh_build_rec(FlatBvh &out, const std::vector<Box> &boxes, uint32_t *id
     p[4] = node_box.mx.x; p[5] = node_box.mx.y; p[6] = node_box.mx.z; p[7] = bits_f(B);
     return me;
 }
-Box bvh_build(FlatBvh &out, const std::vector<Box> &boxes) {
+Box bvh_build(FlatBvh &out, const std::vector<Box> &boxes, BuildPool *shared = nullptr) {
     std::vector<uint32_t> idx(boxes.size());
     for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)i;
+    BuildPool own(host_build_threads() - 1);
+    BuildPool &pool = shared ? *shared : own;
+    const Centers ce = centers_of(boxes, pool);
     Box root;
-    bvh_build_rec(out, boxes, idx.data(), idx.size(), 0, root);
+    bvh_build_rec(out, boxes, ce, idx.data(), idx.size(), 0, root, pool);
     return root;
 }
 
@@ -240,7 +339,7 @@ void leaf_node_boxes(const FlatBvh &ref, std::vector<Box> &boxes) {
 constexpr uint32_t SAH_MAX_DEPTH = 40;
 inline float box_area(const Box &b) { V3 d = b.mx - b.mn; return 2.f * (d.x * d.y + d.y * d.z + d.z * d.x); }
 
-uint32_t sah_build_rec(FlatBvh &out, const std::vector<Box> &boxes, uint32_t *idx, size_t n, uint32_t depth, Box &node_box) {
+uint32_t sah_build_rec(FlatBvh &out, const std::vector<Box> &boxes, const Centers &ce, uint32_t *idx, size_t n, uint32_t depth, Box &node_box, BuildPool &pool) {
     uint32_t me = out.count();
     out.nodes.resize(out.nodes.size() + 8);
     out.depth = std::max(out.depth, depth);
@@ -248,49 +347,77 @@ uint32_t sah_build_rec(FlatBvh &out, const std::vector<Box> &boxes, uint32_t *id
     if (n == 1) { node_box = boxes[idx[0]]; A = (fw::NODE_LEAF << 30) | idx[0]; }
     else if (n == 2) { node_box = box_union(boxes[idx[0]], boxes[idx[1]]); A = (fw::NODE_DOUBLE << 30) | idx[0]; B = idx[1]; }
     else {
-        Box cb{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
-        for (size_t i = 0; i < n; i++) { V3 c = box_center(boxes[idx[i]]); cb.mn = vmin(cb.mn, c); cb.mx = vmax(cb.mx, c); }
-        int best_axis = -1; size_t best_split = 0; float best_cost = 1e38f;
+        const Box EMPTY{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}};
         constexpr int NB = 16;
-        if (depth < SAH_MAX_DEPTH) for (int axis = 0; axis < 3; axis++) {
-            float lo = cb.mn[axis], ext = cb.mx[axis] - lo;
-            if (!(ext > 0.f)) continue;
-            Box bb[NB]; size_t bc[NB];
-            for (int k = 0; k < NB; k++) { bb[k] = {{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}}; bc[k] = 0; }
-            for (size_t i = 0; i < n; i++) {
-                int k = std::min(NB - 1, std::max(0, (int)((box_center(boxes[idx[i]])[axis] - lo) / ext * NB)));
-                bb[k] = box_union(bb[k], boxes[idx[i]]); bc[k]++;
-            }
-            float la[NB], ra[NB]; size_t lc[NB], rc[NB];
-            Box acc{{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}}; size_t cnt = 0;
-            for (int k = 0; k < NB; k++) { if (bc[k]) acc = box_union(acc, bb[k]); cnt += bc[k]; la[k] = cnt ? box_area(acc) : 0.f; lc[k] = cnt; }
-            acc = {{1e30f, 1e30f, 1e30f}, {-1e30f, -1e30f, -1e30f}}; cnt = 0;
-            for (int k = NB - 1; k >= 0; k--) { if (bc[k]) acc = box_union(acc, bb[k]); cnt += bc[k]; ra[k] = cnt ? box_area(acc) : 0.f; rc[k] = cnt; }
-            for (int k = 0; k + 1 < NB; k++) {
-                if (lc[k] == 0 || rc[k + 1] == 0) continue;
-                float cost = la[k] * (float)lc[k] + ra[k + 1] * (float)rc[k + 1];
-                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = (size_t)k; }
+        // the passes over the node's items (the centroids' bounds, then the bins of the three axes) in parts on the free threads: unions
+        // by fmin / fmax and counts are exact, so the merged bins are the sequential ones
+        const int helpers = n >= PAR_PASS_MIN ? pool.take(15) : 0, parts = helpers + 1;
+        Box cb = EMPTY;
+        {
+            std::vector<Box> pcb((size_t)parts, EMPTY);
+            par_parts(n, parts, [&](size_t lo, size_t hi, int k) {
+                Box b = EMPTY;
+                for (size_t i = lo; i < hi; i++) { const uint32_t it = idx[i]; const V3 c{ce.c[0][it], ce.c[1][it], ce.c[2][it]}; b.mn = vmin(b.mn, c); b.mx = vmax(b.mx, c); }
+                pcb[(size_t)k] = b; });
+            for (const Box &b : pcb) { cb.mn = vmin(cb.mn, b.mn); cb.mx = vmax(cb.mx, b.mx); }
+        }
+        int best_axis = -1; size_t best_split = 0; float best_cost = 1e38f;
+        if (depth < SAH_MAX_DEPTH) {
+            struct Bins { Box bb[3][NB]; size_t bc[3][NB]; };
+            std::vector<Bins> pb((size_t)parts);
+            par_parts(n, parts, [&](size_t lo_i, size_t hi_i, int k) {
+                Bins &bn = pb[(size_t)k];
+                for (int axis = 0; axis < 3; axis++) for (int q = 0; q < NB; q++) { bn.bb[axis][q] = EMPTY; bn.bc[axis][q] = 0; }
+                for (int axis = 0; axis < 3; axis++) {
+                    const float lo = cb.mn[axis], ext = cb.mx[axis] - lo;
+                    if (!(ext > 0.f)) continue;
+                    const float *key = ce.c[axis].data();
+                    for (size_t i = lo_i; i < hi_i; i++) {
+                        const uint32_t it = idx[i];
+                        const int q = std::min(NB - 1, std::max(0, (int)((key[it] - lo) / ext * NB)));
+                        bn.bb[axis][q] = box_union(bn.bb[axis][q], boxes[it]); bn.bc[axis][q]++;
+                    }
+                } });
+            for (int axis = 0; axis < 3; axis++) {
+                float lo = cb.mn[axis], ext = cb.mx[axis] - lo;
+                if (!(ext > 0.f)) continue;
+                Box bb[NB]; size_t bc[NB];
+                for (int k = 0; k < NB; k++) { bb[k] = EMPTY; bc[k] = 0; }
+                for (const Bins &bn : pb) for (int k = 0; k < NB; k++) if (bn.bc[axis][k]) { bb[k] = box_union(bb[k], bn.bb[axis][k]); bc[k] += bn.bc[axis][k]; }
+                float la[NB], ra[NB]; size_t lc[NB], rc[NB];
+                Box acc = EMPTY; size_t cnt = 0;
+                for (int k = 0; k < NB; k++) { if (bc[k]) acc = box_union(acc, bb[k]); cnt += bc[k]; la[k] = cnt ? box_area(acc) : 0.f; lc[k] = cnt; }
+                acc = EMPTY; cnt = 0;
+                for (int k = NB - 1; k >= 0; k--) { if (bc[k]) acc = box_union(acc, bb[k]); cnt += bc[k]; ra[k] = cnt ? box_area(acc) : 0.f; rc[k] = cnt; }
+                for (int k = 0; k + 1 < NB; k++) {
+                    if (lc[k] == 0 || rc[k + 1] == 0) continue;
+                    float cost = la[k] * (float)lc[k] + ra[k + 1] * (float)rc[k + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_split = (size_t)k; }
+                }
             }
         }
+        pool.give(helpers);
         size_t half;
         int axis;
         if (best_axis >= 0) {
             axis = best_axis;
             float lo = cb.mn[axis], ext = cb.mx[axis] - lo;
+            const float *key = ce.c[axis].data();
             auto mid = std::stable_partition(idx, idx + n, [&](uint32_t a) {
-                int k = std::min(NB - 1, std::max(0, (int)((box_center(boxes[a])[axis] - lo) / ext * NB)));
+                int k = std::min(NB - 1, std::max(0, (int)((key[a] - lo) / ext * NB)));
                 return (size_t)k <= best_split; });
             half = (size_t)(mid - idx);
         } else {   // all centroids coincide (or depth cap): median split keeps the tree balanced
             V3 e = cb.mx - cb.mn;
             axis = e.x >= e.y ? (e.x >= e.z ? 0 : 2) : (e.y >= e.z ? 1 : 2);
-            std::stable_sort(idx, idx + n, [&](uint32_t a, uint32_t b) { return box_center(boxes[a])[axis] < box_center(boxes[b])[axis]; });
+            const float *key = ce.c[axis].data();
+            par_stable_sort(idx, n, [key](uint32_t a, uint32_t b) { return key[a] < key[b]; }, pool);
             half = n / 2;
         }
         if (half == 0 || half == n) half = n / 2;
         Box lb, rb;
-        sah_build_rec(out, boxes, idx, half, depth + 1, lb);
-        uint32_t right = sah_build_rec(out, boxes, idx + half, n - half, depth + 1, rb);
+        const uint32_t right = build_children(out, n, half, pool, [&](FlatBvh &into, size_t first, size_t count, Box &b) {
+            sah_build_rec(into, boxes, ce, idx + first, count, depth + 1, b, pool); }, lb, rb);
         node_box = box_union(lb, rb);
         A = right;
         B = (uint32_t)axis;     // left child holds the smaller centroids along this axis
@@ -300,11 +427,14 @@ uint32_t sah_build_rec(FlatBvh &out, const std::vector<Box> &boxes, uint32_t *id
     p[4] = node_box.mx.x; p[5] = node_box.mx.y; p[6] = node_box.mx.z; p[7] = bits_f(B);
     return me;
 }
-void sah_build(FlatBvh &out, const std::vector<Box> &boxes) {
+void sah_build(FlatBvh &out, const std::vector<Box> &boxes, BuildPool *shared = nullptr) {
     std::vector<uint32_t> idx(boxes.size());
     for (size_t i = 0; i < idx.size(); i++) idx[i] = (uint32_t)i;
+    BuildPool own(host_build_threads() - 1);
+    BuildPool &pool = shared ? *shared : own;
+    const Centers ce = centers_of(boxes, pool);
     Box root;
-    sah_build_rec(out, boxes, idx.data(), idx.size(), 0, root);
+    sah_build_rec(out, boxes, ce, idx.data(), idx.size(), 0, root, pool);
 }
 
 // ---- the tree as walked on the device: pair nodes (fw_device.h), converted from a FlatBvh.  A DoubleLeaf becomes a
@@ -486,6 +616,7 @@ static uint32_t wide_build_rec(const std::vector<BinNode> &t, int bin, WideBvh &
 static uint32_t wide_convert(const FlatBvh &src, const std::vector<Box> &item_boxes, WideBvh &out) {
     uint32_t A; std::memcpy(&A, &src.nodes[3], 4);
     if ((A >> 30) == fw::NODE_LEAF) return (A & fw::NODE_MASK) < 0x7fffu ? (fw::W_LEAF | (A & fw::NODE_MASK)) : 0xffffffffu;
+    if (item_boxes.size() >= 0x7fffu) return 0xffffffffu;          // 15-bit item references: not encodable (found only at the last leaf otherwise: 90 ms for a million triangles)
     WideBvh local; local.fmt = out.fmt;
     const uint32_t base = out.count();
     std::vector<BinNode> bin;
@@ -596,7 +727,7 @@ struct Workspace {
     // and allocated two dozen multi-GB buffers, 2 s in the caller's timed region (profiles/r03z_oneshot_trace.txt: the first
     // volume frame after suzanne).  The arena only grows, in steps of 1 GiB.
     struct Lane { void *ray_a[2] = {nullptr, nullptr}, *ray_b[2] = {nullptr, nullptr}, *state[2] = {nullptr, nullptr}, *hits = nullptr, *sample_rad = nullptr,
-                       *wcount = nullptr, *park_a = nullptr, *park_b = nullptr, *park_m = nullptr, *pcount = nullptr, *dep_bits = nullptr, *exact_slots = nullptr;
+                       *wcount = nullptr, *park_a = nullptr, *park_b = nullptr, *park_m = nullptr, *pcount = nullptr, *dep_bits = nullptr, *exact_slots = nullptr, *atten = nullptr;
                   hipStream_t stream = nullptr;
                   std::vector<hipEvent_t> events; };
     DevBuf arena;
@@ -857,8 +988,34 @@ struct Flattener {
             boxes[t] = b;
         }
         lap(ms_gather);
-        FlatBvh local;
-        try { sp.box = bvh_build(local, boxes); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); }
+        // Round 5: the reference tree and the walked tree are built at the same time, each in parallel below its big nodes (BuildPool: one budget
+        // of host threads for both), and the three forms of the walked tree — pair nodes, wide f32, wide q8 — are converted side by side.
+        BuildPool pool(host_build_threads() - 1);
+        FlatBvh local, walked;
+        bool nan_error = false;
+        std::exception_ptr ref_error;
+        const bool two = n_tris >= PAR_SUBTREE_MIN && pool.take(1) == 1;
+        auto build_reference = [&] { try { (void)bvh_build(local, boxes, &pool); } catch (NanError &) { nan_error = true; } catch (...) { ref_error = std::current_exception(); } };
+        std::thread ref_thread;
+        if (two) ref_thread = std::thread(build_reference); else build_reference();
+        // the mesh's own box = the reference root's: the union of every triangle's box (fmin / fmax: the same in any order)
+        Box all = boxes[0];
+        for (const Box &b : boxes) all = box_union(all, b);
+        sp.box = all;
+        // the boxes of the walked trees (grown_by: 2^-6 of a typical triangle, at least 2^-14 of the triangle's own extent)
+        std::vector<Box> wboxes = boxes;
+        {
+            const float typ = box_extent(sp.box) / std::sqrt((float)std::max(1u, n_tris));
+            for (Box &b : wboxes) b = grown_by(b, std::fmax(std::ldexp(typ, -6), std::ldexp(box_extent(b), -14)));
+        }
+        const bool sah = use_sah();
+        std::exception_ptr sah_error;
+        if (sah) { try { sah_build(walked, wboxes, &pool); } catch (...) { sah_error = std::current_exception(); } }
+        lap(ms_sah);
+        if (two) { ref_thread.join(); pool.give(1); }
+        if (nan_error) return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor");
+        if (ref_error) std::rethrow_exception(ref_error);
+        if (sah_error) std::rethrow_exception(sah_error);
         {   // ties are resolved by the reference tree's in-order rank, whatever tree is traversed
             std::vector<uint32_t> rk = reference_ranks(local, n_tris);
             tri_rank.insert(tri_rank.end(), rk.begin(), rk.end());
@@ -882,24 +1039,33 @@ struct Flattener {
                 g[0] = gboxes[t].mn.x; g[1] = gboxes[t].mn.y; g[2] = gboxes[t].mn.z; g[4] = gboxes[t].mx.x; g[5] = gboxes[t].mx.y; g[6] = gboxes[t].mx.z;
             }
         }
-        {   // from here on: the boxes of the walked trees (grown_by: 2^-6 of a typical triangle, at least 2^-14 of the triangle's own extent)
-            const float typ = box_extent(sp.box) / std::sqrt((float)std::max(1u, n_tris));
-            for (Box &b : boxes) b = grown_by(b, std::fmax(std::ldexp(typ, -6), std::ldexp(box_extent(b), -14)));
-        }
         lap(ms_gate);
-        if (use_sah()) { FlatBvh sah; sah_build(sah, boxes); local = std::move(sah); }
-        lap(ms_sah);
-        uint32_t root = pair_convert(local, boxes, blas);     // root reference into the shared BLAS array
-        blas_depth = blas.depth;
+        const FlatBvh &wt = sah ? walked : local;      // BVH=median walks the reference's own topology (over the grown boxes)
+        uint32_t root = 0, wr[2] = {0xffffffffu, 0xffffffffu};
+        for (int f = 0; f < 2; f++) { WideBvh &wb = f == 0 ? wblas_f32 : wblas_q8; if (wb.fmt == 0) wb.fmt = f == 0 ? fw::WIDE_F32 : fw::WIDE_Q8; }
+        {
+            std::exception_ptr conv_error[3];
+            auto convert = [&](int which) {
+                try {
+                    if (which == 0) { root = pair_convert(wt, wboxes, blas); blas_depth = blas.depth; }      // root reference into the shared BLAS array
+                    else if (wide_ok[which - 1]) wr[which - 1] = wide_convert(wt, wboxes, which == 1 ? wblas_f32 : wblas_q8);   // the same tree as WIDE nodes, in both encodings (create_scene_impl keeps one, or none)
+                } catch (...) { conv_error[which] = std::current_exception(); }
+            };
+            const int helpers = n_tris >= PAR_SUBTREE_MIN ? pool.take(2) : 0;
+            std::vector<std::thread> th;
+            for (int k = 0; k < helpers; k++) th.emplace_back(convert, k + 1);
+            convert(0);
+            for (int k = helpers; k < 2; k++) convert(k + 1);
+            for (auto &t : th) t.join();
+            pool.give(helpers);
+            for (auto &e : conv_error) if (e) std::rethrow_exception(e);
+        }
         lap(ms_pair);
         sp.aux0 = root; sp.aux1 = tri_base;
-        for (int f = 0; f < 2; f++) {                         // the same tree as WIDE nodes, in both encodings (create_scene_impl keeps one, or none)
-            WideBvh &wb = f == 0 ? wblas_f32 : wblas_q8;
-            if (wb.fmt == 0) wb.fmt = f == 0 ? fw::WIDE_F32 : fw::WIDE_Q8;
+        for (int f = 0; f < 2; f++) {
             if (!wide_ok[f]) continue;
-            const uint32_t wr = wide_convert(local, boxes, wb);
-            if (wr == 0xffffffffu) wide_ok[f] = false;
-            (f == 0 ? sp.wroot_f32 : sp.wroot_q8) = wr;
+            if (wr[f] == 0xffffffffu) wide_ok[f] = false;
+            (f == 0 ? sp.wroot_f32 : sp.wroot_q8) = wr[f];
         }
         lap(ms_wide);
         if (s.normals) sp.flags |= fw::OF_MESH_NORMALS;
@@ -1253,8 +1419,8 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
     }
     if (trace) fprintf(stderr, "[firework] scene_create: build %.2f ms, blob %.2f ms (%zu B), alloc %.2f ms (%s), upload launch %.2f ms\n",
                        tr_build, tr_blob, total, tr_alloc, reused ? "cached" : "hipMalloc", ms_since(tr3));
-    if (trace && !fl.tri.empty()) fprintf(stderr, "[firework] scene_create: meshes (%zu triangles): gather %.2f ms | reference tree + ranks %.2f | gate boxes %.2f | SAH %.2f | pair nodes %.2f | wide nodes (f32 + q8) %.2f\n",
-                                          fl.tri.size() / 12, fl.ms_gather, fl.ms_ref, fl.ms_gate, fl.ms_sah, fl.ms_pair, fl.ms_wide);
+    if (trace && !fl.tri.empty()) fprintf(stderr, "[firework] scene_create: meshes (%zu triangles, %d host threads): gather %.2f ms | SAH tree, the reference tree beside it %.2f | wait for the reference tree + ranks %.2f | gate boxes %.2f | pair + wide f32 + wide q8 side by side %.2f\n",
+                                          fl.tri.size() / 12, host_build_threads(), fl.ms_gather, fl.ms_sah, fl.ms_ref, fl.ms_gate, fl.ms_pair + fl.ms_wide);
     if (rc) { delete sc; return rc; }
     const uint8_t *base = (const uint8_t *)sc->data.p;
     fw::DScene &d = sc->d;
@@ -1391,7 +1557,9 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     int n_lanes = (p->use_bvh || sc->n_defer > 0) ? 2 : 1;
     if (O.streams >= 1) n_lanes = std::min(O.streams, (int)Workspace::MAX_LANES);
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, p->samples);
-    uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch(O, ws->arena.bytes) / (uint32_t)n_lanes;
+    // EXACT_PRODUCT: 160 more bytes per slot (ten attenuation records) where the scene has no chain state: half the default batch
+    const bool exact_product = O.exact_product && (sc->chain_bits == 0 || O.no_chain);
+    uint32_t budget = p->paths_per_batch ? p->paths_per_batch : default_paths_per_batch(O, ws->arena.bytes) / (uint32_t)n_lanes / (exact_product ? 2u : 1u);
     uint32_t spp_b = std::max<uint32_t>(1u, budget / n_pix);
     spp_b = std::min(spp_b, (p->samples + (uint32_t)n_lanes - 1) / (uint32_t)n_lanes);     // at least one batch per lane
     uint64_t paths64 = (uint64_t)n_pix * spp_b;
@@ -1452,6 +1620,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             put(L.hits, (size_t)cap * 8);
             put(L.sample_rad, (size_t)cap * 16);              // indexed by home slot
             put(L.dep_bits, ((size_t)cap + 31) / 32 * 4);     // one bit per slot: "a radiance record was written here" (black environments)
+            if (exact_product && !fused_req) put(L.atten, (size_t)cap * (fw::MAX_SEGMENTS - 1) * fw::B_ATTEN); else L.atten = nullptr;
             if (exact_mode) put(L.exact_slots, 2 * (size_t)max_paths * 4 + 64);   // two lists of at most every ray of a segment, + the counters
             put(L.wcount, (size_t)(fw::MAX_SEGMENTS + 1) * q.n_waves * 4);
             if (park_meshes) {     // rays handed from k_extend_scan / k_extend_tlas_park to k_blas*: 40 B per slot
@@ -1522,6 +1691,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.wblas_fmt = sc->wblas_fmt; cfg.wtlas_fmt = sc->wtlas_fmt; cfg.wblas_nodes = sc->wblas_nodes; cfg.wtlas_nodes = sc->wtlas_nodes;
     cfg.wblas_depth = sc->wblas_depth; cfg.wtlas_depth = sc->wtlas_depth;
     cfg.exact_form = O.exact_form;
+    cfg.debug_wide_levels = 0;
+#if FW_AB
+    cfg.debug_wide_levels = (uint32_t)O.debug_wide_levels;
+#endif
     cfg.ref_tlas_nodes = sc->tlas_nodes; cfg.ref_blas_nodes = sc->blas_nodes; cfg.ref_tlas_depth = sc->ref_tlas_depth; cfg.ref_blas_depth = sc->ref_blas_depth;
     // k_shade's list entries are 16-bit queue positions: longer queues (cap > 65536: never with the default geometry) shade in line
     // Default: the cheap loop alone where the scene has nothing expensive (cornell k_shade -5 %), everything in line otherwise — the
@@ -1599,6 +1772,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         if (timing && ev_next[l] == 0) (void)hipEventRecord(L.events[0], ls);
         fr.sample0 = first_sample + b * spp_b;
         fr.dep_bits = (uint32_t *)L.dep_bits;
+        fr.atten = (fr.chain_bits == 0 && exact_product && !fused_req) ? (float4 *)L.atten : nullptr; fr.atten_stride = cap;
         if (fr.skip_zero_deposits) HIPCHK(hipMemsetAsync(fr.dep_bits, 0, ((size_t)cap + 31) / 32 * 4, ls));
         if (exact_mode) {
             fr.ex.slots[0] = (uint32_t *)L.exact_slots; fr.ex.slots[1] = fr.ex.slots[0] + max_paths;
@@ -1701,6 +1875,11 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         if (gamma_rgb) std::memcpy(gamma_rgb, ho + off_g, (size_t)n_pix * 12);
         if (linear_rgb) std::memcpy(linear_rgb, ho + off_l, (size_t)n_pix * 12);
     }
+#if FW_AB
+    if (const uint32_t ew = fw::take_error_word())      // the A/B build's device-side guards (fw_kernels.hip: g_err_word): the frame is not to be trusted
+        return fail(FW_ERR_HIP, std::string("device error word: ") + ((ew & 1u) ? "LDS traversal stack overflow (a push beyond the levels the launch reserved) " : "") +
+                                    ((ew & 2u) ? "a walk kernel's wave made no progress for 2^24 rounds (left its loop) " : ""));
+#endif
     if (trace) fprintf(stderr, "[firework] render: enqueue %.2f ms | counters copy queued +%.2f | output copies queued +%.2f | sync + host memcpy returned +%.2f\n",
                        std::chrono::duration<double, std::milli>(tq0 - wall0).count(), t_counts, t_outs, since(tq0));
     const auto wall1 = std::chrono::steady_clock::now();
@@ -1723,7 +1902,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             stats->bytes_raygen = S * ray0 + (fr.pixel_ids ? S * 4 : 0);
             const uint64_t medium = sc->d.has_medium ? later * 4 : 0;       // the path's home slot (RNG key of the medium's draw)
             const uint64_t b_state = fr.chain_bits ? fw::B_STATE_CHAIN : fw::B_STATE;
-            const uint64_t shade_in = rd_ray + later * b_state, shade_out = survivors * (fw::B_RAY + b_state) + stats->deposits * fw::B_DEPOSIT;
+            // (EXACT_PRODUCT: one attenuation record written per survivor; a depositing path reads back its own — at most its length: not counted)
+            const uint64_t shade_in = rd_ray + later * b_state, shade_out = survivors * (fw::B_RAY + b_state + (fr.atten ? fw::B_ATTEN : 0u)) + stats->deposits * fw::B_DEPOSIT;
             if (fused) { stats->bytes_extend = 0; stats->bytes_shade = shade_in + shade_out; }
             else {
                 stats->bytes_extend = rd_ray + medium + stats->rays * b_hit + stats->parked_rays * 2 * fw::B_PARK;
@@ -1853,6 +2033,26 @@ int fw_selftest_wide_bvh(const float *boxes, uint32_t n, int format, uint32_t *v
     }
     catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
     catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_selftest_wide_bvh"); }
+}
+
+// CPU-only diagnostic (ABI v7): the host builders — the reference's median-split tree (bvh.rs:21-71) and the binned-SAH tree that is walked —
+// over n item boxes with `threads` host threads (1 = the sequential recursion); hashes[0..1] = FNV-1a of the two node arrays, stats = nodes and
+// depth of each.  The parallel builds must reproduce the sequential ones bit for bit (tests/test_host_build_cpu.py).
+int fw_selftest_bvh_build(const float *boxes, uint32_t n, int threads, uint64_t hashes[2], uint32_t stats[4]) {
+    if (!boxes || n == 0 || threads < 1 || !hashes || !stats) return fail(FW_ERR_BAD_ARG, "bad argument");
+    try {
+        std::vector<Box> b(n);
+        for (uint32_t i = 0; i < n; i++) b[i] = Box{{boxes[6 * i], boxes[6 * i + 1], boxes[6 * i + 2]}, {boxes[6 * i + 3], boxes[6 * i + 4], boxes[6 * i + 5]}};
+        auto fnv = [](const std::vector<float> &v) { uint64_t h = 1469598103934665603ull; const uint8_t *p = (const uint8_t *)v.data(); for (size_t i = 0; i < v.size() * 4; i++) { h ^= p[i]; h *= 1099511628211ull; } return h; };
+        FlatBvh ref, sah;
+        { BuildPool pool(threads - 1); try { (void)bvh_build(ref, b, &pool); } catch (NanError &) { return fail(FW_ERR_NAN_BBOX, "Float comparison failed in BVH constructor"); } }
+        { BuildPool pool(threads - 1); sah_build(sah, b, &pool); }
+        hashes[0] = fnv(ref.nodes); hashes[1] = fnv(sah.nodes);
+        stats[0] = ref.count(); stats[1] = ref.depth; stats[2] = sah.count(); stats[3] = sah.depth;
+        return FW_OK;
+    }
+    catch (std::bad_alloc &) { return fail(FW_ERR_OOM, "host allocation failed"); }
+    catch (...) { return fail(FW_ERR_BAD_ARG, "unexpected exception in fw_selftest_bvh_build"); }
 }
 
 #if FW_AB

@@ -317,6 +317,9 @@ int fw_selftest_libm(int device, int fn, uint32_t n, const float *x, const float
      STREAMS=n, WAVES=n, PATHS_PER_BATCH=n            batches in flight, wave queues, pool size
      NO_DEFER NO_HIT4 NO_HOIST NO_LDS_TABLES NO_LDS_TREES NO_LDS_TRIS NO_SHORT_RAYS NO_TILE_ORDER NO_ZERO_SKIP
      DEP_PIXEL_MAJOR DEP_SLOT_MAJOR NO_CHAIN          the layout choices the tests force both ways
+     EXACT_PRODUCT=1       scenes with a varying texture keep every scattering's attenuation (16 B per segment) and multiply back to front when
+                           a path deposits — render.rs:23-28's own association, the pre-gamma means then equal the CPU oracle's bit for bit
+                           (scenes of constant textures always do: their 8-byte chain state).  Default off: the running product, ~1 ulp away
      TRACE, DUMP_PATH=file                            host-side timing trace; one path's records (tools/diverge.py)
    Returns FW_ERR_BAD_ARG for a name this build does not know. */
 int fw_set_option(const char *name, const char *value);
@@ -327,6 +330,12 @@ int fw_set_option(const char *name, const char *value);
    item's own box bit for bit), free slots unhittable.  violations = 0 is the only acceptable answer; stats = nodes, leaves,
    free slots, depth. */
 int fw_selftest_wide_bvh(const float *boxes, uint32_t n, int format, uint32_t *violations, uint32_t stats[4]);
+
+/* Diagnostic, CPU only (ABI v7): the host-side tree builders over n item boxes (n x 6 floats) with `threads` host threads — the reference's
+   median-split tree (bvh.rs:21-71: what fixes tie ranks and gate boxes) and the binned-SAH tree the device walks.  hashes = FNV-1a of the
+   two node arrays, stats = nodes and depth of the median tree, nodes and depth of the SAH tree.  Scene creation builds a mesh's trees in
+   parallel (the reference builds inside its timed region, main.rs:40-44, on one thread); any thread count must give the one-thread trees. */
+int fw_selftest_bvh_build(const float *boxes, uint32_t n, int threads, uint64_t hashes[2], uint32_t stats[4]);
 
 #ifdef __cplusplus
 }

@@ -23,3 +23,11 @@ for bvh in (False, True):
         for i in bad[:3]:
             print("   pixel", int(i), "gpu u8", g.rgb8[i], "cpu u8", c.rgb8[i], "gpu linear", g.linear[i], "cpu linear", c.linear[i], "rel", np.abs(g.linear[i] - c.linear[i]) / np.maximum(np.abs(c.linear[i]), 1e-9))
 _lib.set_option("NO_CHAIN", None)
+# round 5: the same seed with the attenuations multiplied back to front (option EXACT_PRODUCT): the pre-gamma means must be the oracle's bits
+_lib.set_option("EXACT_PRODUCT", "1")
+for bvh in (False, True):
+    r = Renderer.default().width(60).height(40).samples(6).use_bvh(bvh).camera(cam).seed(seed * 7919)
+    g = r.render_full(sc); c = ob.render(sc, r)
+    print("EXACT_PRODUCT bvh", bvh, "u8 diffs", int((g.rgb8 != c.rgb8).sum()), "linear equal bit for bit", bool(np.array_equal(g.linear, c.linear.astype(np.float32))),
+          "max abs diff", float(np.abs(g.linear - c.linear).max()), "rays equal", [int(x) for x in g.stats["rays_per_depth"]] == [int(x) for x in c.stats["rays_per_depth"]])
+_lib.set_option("EXACT_PRODUCT", None)
