@@ -396,15 +396,20 @@ __shared__ float g_ts[8 * 64];
 #endif
 
 #ifndef FW_XCD_SWIZZLE
-#define FW_XCD_SWIZZLE 0
+#define FW_XCD_SWIZZLE 1
 #endif
 // Which queue a single-wave workgroup takes.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b mod 8), so with w = b the
-// waves resident on one XCD own every 8th queue; FW_XCD_SWIZZLE=1 gives XCD x the contiguous eighth [x n/8, (x+1) n/8) instead (timing
-// experiment, round 5: neighbouring windows of the path arrays per XCD, for its L2 TLB).  Any bijection is correct: queues are private.
+// waves resident on one XCD own every 8th queue — eight XCDs' address translation and L2s all working on the same stretch of every path
+// array.  Round 5: XCD x takes the contiguous eighth [x n/8, (x+1) n/8) of the queues instead, so the windows its waves stream are
+// neighbours.  Interleaved on one box (profiles/r05d_shade_ablations.txt): cornell 34.0 -> 32.3 ms (k_extend 14.3 -> 13.75, k_shade 19.3 ->
+// 19.05 exclusive, and the two batches in flight overlap better), hdri 33.9 -> 33.2; on a second box (profiles/r05e_xcd_ab.txt) volume, suzanne and teapot
+// gain 1-1.5 % and cornell's runs scatter by more than the difference.  Any bijection is correct: queues are private.
 __device__ __forceinline__ uint32_t wave_index() {
 #if FW_XCD_SWIZZLE
+    // (big launches only: with a few hundred queues per XCD a contiguous eighth is a contiguous piece of the IMAGE, and one XCD gets the
+    // expensive pixels — random_spheres, 5 600 queues: 1.65 -> 1.77 ms, profiles/r05e_xcd_ab.txt)
     const uint32_t per = gridDim.x >> 3;
-    if ((gridDim.x & 7u) == 0u) return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((gridDim.x & 7u) == 0u && gridDim.x >= 16384u) return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 #endif
     return blockIdx.x * (WB / 64) + (threadIdx.x >> 6);
 }

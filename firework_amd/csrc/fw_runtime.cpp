@@ -966,31 +966,38 @@ struct Flattener {
         tri.resize(tri.size() + (size_t)n_tris * 12);
         if (attr) any_attr = true;
         tri_attr.resize(tri.size(), 0.f);
-        for (uint32_t t = 0; t < n_tris; t++) {
-            V3 p[3];
-            for (int k = 0; k < 3; k++) {
-                uint32_t vi = s.indices[3 * t + k];
-                if (vi >= s.n_verts) return fail(FW_ERR_BAD_ARG, "vertex index out of range");
-                p[k] = {s.verts[3 * vi], s.verts[3 * vi + 1], s.verts[3 * vi + 2]};
-                float *o = &tri[(size_t)(tri_base + t) * 12 + 4 * k];
-                o[0] = p[k].x; o[1] = p[k].y; o[2] = p[k].z;
-                o[3] = s.uvs ? s.uvs[2 * vi] : (k == 1 ? 1.f : 0.f);        // default uvs (0,0),(1,0),(0,1) mesh.rs:107
-                float *a = &tri_attr[(size_t)(tri_base + t) * 12 + 4 * k];
-                if (s.normals) { a[0] = s.normals[3 * vi]; a[1] = s.normals[3 * vi + 1]; a[2] = s.normals[3 * vi + 2]; }
-                a[3] = s.uvs ? s.uvs[2 * vi + 1] : (k == 2 ? 1.f : 0.f);
-            }
-            Box b{vmin(p[0], p[1]), vmax(p[0], p[1])};               // from_two_points(p0,p1).expand_to_point(p2)
-            b = {vmin(b.mn, p[2]), vmax(b.mx, p[2])};
-            V3 size = b.mx - b.mn;
-            if (std::fabs(size.x) < 0.001f) { b.mn.x -= 0.001f; b.mx.x += 0.001f; }
-            if (std::fabs(size.y) < 0.001f) { b.mn.y -= 0.001f; b.mx.y += 0.001f; }
-            if (std::fabs(size.z) < 0.001f) { b.mn.z -= 0.001f; b.mx.z += 0.001f; }
-            boxes[t] = b;
+        BuildPool pool(host_build_threads() - 1);
+        std::atomic<bool> bad_index{false};
+        {
+            const int helpers = n_tris >= PAR_PASS_MIN ? pool.take(15) : 0;
+            par_parts(n_tris, helpers + 1, [&](size_t t_lo, size_t t_hi, int) {
+                for (size_t t = t_lo; t < t_hi; t++) {
+                    V3 p[3];
+                    for (int k = 0; k < 3; k++) {
+                        uint32_t vi = s.indices[3 * t + k];
+                        if (vi >= s.n_verts) { bad_index = true; return; }
+                        p[k] = {s.verts[3 * vi], s.verts[3 * vi + 1], s.verts[3 * vi + 2]};
+                        float *o = &tri[(size_t)(tri_base + t) * 12 + 4 * k];
+                        o[0] = p[k].x; o[1] = p[k].y; o[2] = p[k].z;
+                        o[3] = s.uvs ? s.uvs[2 * vi] : (k == 1 ? 1.f : 0.f);        // default uvs (0,0),(1,0),(0,1) mesh.rs:107
+                        float *a = &tri_attr[(size_t)(tri_base + t) * 12 + 4 * k];
+                        if (s.normals) { a[0] = s.normals[3 * vi]; a[1] = s.normals[3 * vi + 1]; a[2] = s.normals[3 * vi + 2]; }
+                        a[3] = s.uvs ? s.uvs[2 * vi + 1] : (k == 2 ? 1.f : 0.f);
+                    }
+                    Box b{vmin(p[0], p[1]), vmax(p[0], p[1])};               // from_two_points(p0,p1).expand_to_point(p2)
+                    b = {vmin(b.mn, p[2]), vmax(b.mx, p[2])};
+                    V3 size = b.mx - b.mn;
+                    if (std::fabs(size.x) < 0.001f) { b.mn.x -= 0.001f; b.mx.x += 0.001f; }
+                    if (std::fabs(size.y) < 0.001f) { b.mn.y -= 0.001f; b.mx.y += 0.001f; }
+                    if (std::fabs(size.z) < 0.001f) { b.mn.z -= 0.001f; b.mx.z += 0.001f; }
+                    boxes[t] = b;
+                } });
+            pool.give(helpers);
         }
+        if (bad_index) return fail(FW_ERR_BAD_ARG, "vertex index out of range");
         lap(ms_gather);
         // Round 5: the reference tree and the walked tree are built at the same time, each in parallel below its big nodes (BuildPool: one budget
         // of host threads for both), and the three forms of the walked tree — pair nodes, wide f32, wide q8 — are converted side by side.
-        BuildPool pool(host_build_threads() - 1);
         FlatBvh local, walked;
         bool nan_error = false;
         std::exception_ptr ref_error;
@@ -1034,10 +1041,13 @@ struct Flattener {
             std::vector<Box> gboxes = boxes;
             leaf_node_boxes(local, gboxes);
             tri_gate.resize(tri.size() / 12 * 8, 0.f);
-            for (uint32_t t = 0; t < n_tris; t++) {
-                float *g = &tri_gate[(size_t)(tri_base + t) * 8];
-                g[0] = gboxes[t].mn.x; g[1] = gboxes[t].mn.y; g[2] = gboxes[t].mn.z; g[4] = gboxes[t].mx.x; g[5] = gboxes[t].mx.y; g[6] = gboxes[t].mx.z;
-            }
+            const int helpers = n_tris >= PAR_PASS_MIN ? pool.take(15) : 0;
+            par_parts(n_tris, helpers + 1, [&](size_t t_lo, size_t t_hi, int) {
+                for (size_t t = t_lo; t < t_hi; t++) {
+                    float *g = &tri_gate[(size_t)(tri_base + t) * 8];
+                    g[0] = gboxes[t].mn.x; g[1] = gboxes[t].mn.y; g[2] = gboxes[t].mn.z; g[4] = gboxes[t].mx.x; g[5] = gboxes[t].mx.y; g[6] = gboxes[t].mx.z;
+                } });
+            pool.give(helpers);
         }
         lap(ms_gate);
         const FlatBvh &wt = sah ? walked : local;      // BVH=median walks the reference's own topology (over the grown boxes)
@@ -1588,7 +1598,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     if (!p->use_bvh && n_lanes > 1) want_waves = chunks >= (1u << 20) ? unit : (uint32_t)sc->n_cus * 48u;
     if (O.waves > 0) want_waves = (uint32_t)O.waves;
     q.n_waves = std::max(4u, std::min(want_waves, (max_paths + 511u) / 512u));
-    q.n_waves = (q.n_waves + 3u) & ~3u;
+    q.n_waves = (q.n_waves + 7u) & ~7u;       // a multiple of 8: one contiguous eighth of the queues per XCD (fw_kernels.hip: wave_index)
     uint32_t chunks_per_wave = (max_paths + q.n_waves * 64u - 1) / (q.n_waves * 64u);
     q.cpw_shift = 0;
     while ((1u << q.cpw_shift) < chunks_per_wave) q.cpw_shift++;      // power of two: chunk -> (wave, row) is a shift

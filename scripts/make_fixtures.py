@@ -12,6 +12,8 @@
                                example still matches src/ (cornell_box, suzanne, volume, conics, Earth, teapot):
                                the pixels tests/test_reference_renders.py renders with the oracle at the example's own
                                resolution and spp (pixel_ids = the same lattice)
+                               + random_spheres.png: where it leaves the sky (silhouettes of the three big spheres, the horizon) and
+                               every 2nd pixel of its lower rows (the checker ground)
   scenes/uvmap.png          <- /root/reference/uvmap.png           (ImageTexture of conics.rs / earth.rs)
   scenes/teapot_mesh.npz    <- /root/reference/scenes/teapot.yml   (4 TriangleMeshes with vertex normals = tobj 1.0's
                                output for teapot.obj; 6 320 triangles)
@@ -78,6 +80,32 @@ def main():
     # ... and the 200x200 window around the MetalMat sphere (albedo .8 .8 .9, roughness 10) at (0, 1.5, 1.45): nothing random on it either
     lat["part2_metal_window"] = np.ascontiguousarray(im[496:696, 248:448])
     lat["part2_metal_window_meta"] = np.array([600, 800, 248, 496, 448, 696], np.int32)
+    # random_spheres.png (960x540, examples/random_spheres.rs): the small spheres come from tiny_rng (not in the tree), the three big spheres, the
+    # ground sphere and its CheckerTexture do not.  Round 5: (a) where the image leaves the sky — the silhouettes of the metal, the diffuse and
+    # the glass sphere and the horizon of the ground sphere, measured as the first pixel along a scanline that differs from the sky colour of
+    # its row (taken at column 940) by more than 40 grey levels in sum — and (b) every 2nd pixel of the rows 300..539, where the checker's
+    # cells are several pixels wide.  tests/test_reference_renders.py fits nothing to them: it renders the oracle with a camera and compares.
+    im = np.asarray(Image.open(f"{REF}/random_spheres.png").convert("RGB"), np.uint8)
+    assert im.shape == (540, 960, 3)
+    f = im.astype(np.float32)
+
+    def edge_row(y, xs, thr=40):
+        for x in xs:
+            if np.abs(f[y, x] - f[y, 940]).sum() > thr:
+                return x
+
+    def edge_col(x, ys, thr=40):
+        for y in ys:
+            if np.abs(f[y, x] - f[y, 940]).sum() > thr:
+                return y
+    lat["random_spheres_metal_edge"] = np.array([(edge_row(y, range(930, 500, -1)), y) for y in range(110, 158, 3)] +
+                                                [(x, edge_col(x, range(40, 200))) for x in range(560, 700, 8)], np.int32)      # (x, y) of the first non-sky pixel
+    lat["random_spheres_diffuse_edge"] = np.array([(edge_row(y, range(5, 500)), y) for y in range(112, 158, 3)] +
+                                                  [(x, edge_col(x, range(40, 200))) for x in range(362, 402, 5)], np.int32)
+    lat["random_spheres_glass_edge"] = np.array([(x, edge_col(x, range(40, 200))) for x in range(455, 497, 3)], np.int32)
+    lat["random_spheres_horizon"] = np.array([(x, edge_col(x, range(100, 300), 25)) for x in (5, 60, 100, 150, 200, 250, 300, 800, 850, 900, 950)], np.int32)
+    lat["random_spheres_ground"] = np.ascontiguousarray(im[300:540:2, 0:960:2])
+    lat["random_spheres_ground_meta"] = np.array([960, 540, 0, 300, 2], np.int32)      # width, height, x0, y0, stride
     np.savez_compressed(f"{ROOT}/tests/golden/reference_png_lattice.npz", **lat)
     shutil.copyfile(f"{REF}/uvmap.png", f"{ROOT}/scenes/uvmap.png")
 

@@ -22,10 +22,12 @@ Each image is compared at gamma 2.2 (render.rs:214, today's default) AND at gamm
   part2_final.png  part2_all.rs 600x800 @10000 BVH  2.2      the TurbulenceTexture sphere's pattern (Perlin noise, turbulence) and the MetalMat sphere's
                                                              luminance profile (round 4): box heights and the small spheres come from tiny_rng, the example is API-stale
 
-Not usable: random_spheres.png (its camera is not the example's: the horizon sits on row 169 instead of 182, the metal sphere
-has radius 119 px instead of 106 and its centre is 19 px further right — not a pure zoom — and the checker squares are larger;
-with the layout from tiny_rng on top, nothing in it can be compared without fitting four or more unknowns), hdri_test.png
-(its .hdr is not in the tree), heightmap.png (out of scope).
+  random_spheres.png  random_spheres.rs 960x540 @32  2.2     round 5: the CheckerTexture of the ground (texture.rs:57-73: sign of the product of three sines) and the
+                                                             camera model — with the example's cam_pos at (12, 2, 3) (the PNG predates today's (13, 2, 3), like volume.png
+                                                             its radii): silhouettes of the three big spheres and the horizon within 1 px rms, 17 px with today's camera;
+                                                             the small spheres come from tiny_rng and are not compared
+
+Not usable: hdri_test.png (its .hdr is not in the tree), heightmap.png (out of scope).
 """
 import os
 
@@ -206,3 +208,94 @@ def test_part2_final_png_pins_the_metal_sphere(oracle):
     print(f"\npart2_final.png metal sphere: strip profile correlation {c_metal:.3f} (a Lambertian in its place: {c_lambert:.3f}), mean strip difference {d_metal:.1f} grey levels")
     assert c_metal > 0.99 and d_metal < 14.0
     assert c_lambert < 0.6
+
+
+def test_random_spheres_png_pins_the_checker_and_its_camera(oracle):
+    """random_spheres.png (examples/random_spheres.rs:14-67).  Its small spheres come from tiny_rng::Rng (not in the tree), but the three big
+    spheres, the ground sphere (r = 1000 at (0, -1000, -1)) and the ground's CheckerTexture(odd (.2,.4,.1), even (.9,.9,.9), scale 10) do not.
+    Nothing is fitted here.  Two oracle renders at the PNG's 960x540 with the example's look_at (origin) and fov (30, the default), one sample
+    per pixel, pinhole (the PNG's aperture 0.1 blurs an edge by ~1 px at these distances):
+      * an id image — every object an EmissiveMat of its own colour: the PNG's silhouette points (where a scanline leaves the sky: 34 on the
+        metal sphere, 24 on the diffuse one, 14 on the glass one's visible arc, 11 on the horizon) must lie within 2 px of the object's outline;
+      * the ground alone with its checker as an EMISSIVE texture, so that a pixel is exactly the texture's value at the oracle's own hit
+        point (sphere.rs:31-60 + texture.rs:57-73 restated): green / white must be what the PNG shows on its lower rows.
+    With cam_pos (12, 2, 3) both hold (outline error < 2 px at every point; 97 % of the confidently coloured ground pixels away from cell
+    borders — the rest are the small spheres' shadows and reflections); with today's example value (13, 2, 3) neither does (17 px; 57 %, i.e.
+    chance).  Found by a least-squares fit of the position alone, which lands at (11.98, 2.00, 2.98): scripts history, DESIGN.md §2."""
+    from firework_amd.api import (CameraSettings, CheckerTexture, ColorEnv, EmissiveMat, RenderObject, Renderer, Scene, Sphere)
+    W, H = 960, 540
+    edges = {k: LATTICE["random_spheres_" + k].astype(np.int64) for k in ("metal_edge", "diffuse_edge", "glass_edge", "horizon")}
+    ground = LATTICE["random_spheres_ground"].astype(np.int32)
+    gw, gh, gx0, gy0, gstride = (int(x) for x in LATTICE["random_spheres_ground_meta"])
+    assert (gw, gh) == (W, H)
+
+    def render(scene, cam_pos, pixel_ids=None):
+        cam = CameraSettings.default().cam_pos(cam_pos).look_at((0.0, 0.0, 0.0))      # fov 30, aperture 0 (defaults, camera.rs:18-36)
+        r = Renderer.default().width(W).height(H).samples(1).use_bvh(False).camera(cam)
+        return oracle.render(scene, r, pixel_ids=pixel_ids)
+
+    def id_scene():
+        sc = Scene.new()
+        cols = [(0.1, 0.1, 0.1), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)]      # ground, glass (0,1,0), diffuse (-4,1,0), metal (4,1,0)
+        mats = [sc.add_material(EmissiveMat.with_color(c)) for c in cols]
+        sc.add_object(RenderObject.new(Sphere.new(1000.0, mats[0])).position(0.0, -1000.0, -1.0))
+        for m, x in ((mats[1], 0.0), (mats[2], -4.0), (mats[3], 4.0)):
+            sc.add_object(RenderObject.new(Sphere.new(1.0, m)).position(x, 1.0, 0.0))
+        sc.set_environment(ColorEnv.new((1.0, 1.0, 1.0)))
+        return sc
+
+    def outline_errors(cam_pos):
+        img = render(id_scene(), cam_pos).rgb8.reshape(H, W, 3)
+        ids = np.where(img[..., 0] > 250, np.where(img[..., 1] > 250, 9, 1), np.where(img[..., 1] > 250, 2, np.where(img[..., 2] > 250, 3, 0)))   # 9 = sky
+        worst = {}
+        for key, obj in (("metal_edge", 3), ("diffuse_edge", 2), ("glass_edge", 1), ("horizon", 0)):
+            errs = []
+            for x, y in edges[key]:
+                # distance (in pixels, up to 30) from the PNG's first non-sky pixel to the nearest place where the id image switches between sky
+                # and this object along the row or the column
+                best = 30
+                for d in range(0, 30):
+                    hit = False
+                    for xx, yy in ((x - d, y), (x + d, y), (x, y - d), (x, y + d)):
+                        if 1 <= xx < W - 1 and 1 <= yy < H - 1:
+                            n = ids[yy - 1:yy + 2, xx - 1:xx + 2]
+                            if (n == obj).any() and (n == 9).any():
+                                hit = True
+                    if hit:
+                        best = d
+                        break
+                errs.append(best)
+            worst[key] = (float(np.mean(errs)), int(np.max(errs)))
+        return worst
+
+    good, today = outline_errors((12.0, 2.0, 3.0)), outline_errors((13.0, 2.0, 3.0))
+    print("outline errors (mean, max px) with cam_pos (12,2,3):", good, "| with (13,2,3):", today)
+    assert all(v[1] <= 2 for v in good.values()), good
+    assert min(v[0] for k, v in today.items() if k != "horizon") > 8, today
+
+    # the checker: PNG classes on the lattice of the lower rows
+    r_, g_, b_ = ground[..., 0], ground[..., 1], ground[..., 2]
+    green = (np.abs(r_ - 88) < 28) & (g_ > 118) & (g_ < 172) & (np.abs(b_ - 88) < 28)        # odd (.2,.4,.1) under the sky's light: [88, 136-152, 88] in the PNG
+    white = (np.abs(r_ - 184) < 26) & (g_ > 188) & (g_ < 230) & (b_ > 222)                   # even (.9,.9,.9): [184, 200-216, 232-248]
+    cls = np.where(green, -1, np.where(white, 1, 0))
+    ys, xs = np.meshgrid(gy0 + gstride * np.arange(ground.shape[0]), gx0 + gstride * np.arange(ground.shape[1]), indexing="ij")
+    pix = (ys * W + xs).reshape(-1).astype(np.uint32)
+
+    def checker_agreement(cam_pos):
+        sc = Scene.new()
+        tex = CheckerTexture.with_colors((0.2, 0.4, 0.1), (0.9, 0.9, 0.9), 10.0)
+        m = sc.add_material(EmissiveMat.new(tex))
+        sc.add_object(RenderObject.new(Sphere.new(1000.0, m)).position(0.0, -1000.0, -1.0))
+        out = render(sc, cam_pos, pix).linear.reshape(ground.shape)
+        pred = np.where(out[..., 0] > 0.5, 1, -1)                    # even = white = 0.9, odd = green: r = 0.2
+        # away from the cells' borders: a pixel whose four diagonal neighbours on the lattice (2 px away) are the same cell in the oracle's image
+        inner = np.zeros_like(pred, bool)
+        inner[1:-1, 1:-1] = (pred[1:-1, 1:-1] == pred[:-2, :-2]) & (pred[1:-1, 1:-1] == pred[2:, 2:]) & (pred[1:-1, 1:-1] == pred[:-2, 2:]) & (pred[1:-1, 1:-1] == pred[2:, :-2])
+        sel = (cls != 0) & inner
+        return float((pred[sel] == cls[sel]).mean()), int(sel.sum())
+
+    a_good, n_good = checker_agreement((12.0, 2.0, 3.0))
+    a_today, _ = checker_agreement((13.0, 2.0, 3.0))
+    print(f"checker: {a_good:.4f} of {n_good} classified ground pixels agree with cam_pos (12,2,3); {a_today:.4f} with (13,2,3)")
+    assert n_good > 15000 and a_good >= 0.96
+    assert a_today < 0.70
