@@ -320,6 +320,7 @@ def one_shot_cold(args):
         code = ("import sys, time, json; sys.path.insert(0, %r)\n"
                 "from firework_amd import scenes, _lib\n"
                 "s, r = scenes.config(%r, %r, %r, %r); sd = s.to_desc()\n"
+                "t0 = time.perf_counter(); import torch; torch_ms = (time.perf_counter() - t0) * 1e3\n"      # the Python host's plumbing, not the library
                 "t0 = time.perf_counter(); _lib.load(); load_ms = (time.perf_counter() - t0) * 1e3\n"
                 "init_ms = 0.0\n"
                 "if %r:\n"
@@ -327,7 +328,7 @@ def one_shot_cold(args):
                 "t0 = time.perf_counter(); res = _lib.render_scene(sd, r); dt = (time.perf_counter() - t0) * 1e3\n"
                 "st = res.stats\n"
                 "out = dict(ms_wall=dt, ms_library=st['ms_wall'], ms_scene=st['ms_scene'], ms_render=st['ms_render'], ms_d2h=st['ms_d2h'], mrays_per_s=st['rays'] / dt / 1e3,\n"
-                "           ms_library_load=load_ms, ms_fw_init=init_ms, ms_cold_total=load_ms + init_ms + dt)\n"
+                "           ms_import_torch=torch_ms, ms_library_load=load_ms, ms_fw_init=init_ms, ms_cold_total=load_ms + init_ms + dt)\n"
                 "seq = []\n"
                 "for name in (%r):\n"
                 "    s2, r2 = scenes.config(name); sd2 = s2.to_desc(); w = []\n"
@@ -344,12 +345,12 @@ def one_shot_cold(args):
         return d
     try:
         d = child(True)
-        d["region"] = ("first fw_render_scene call of a fresh process after fw_init: ms_wall = scene + render + D2H; before it ms_library_load (dlopen: no HIP call since "
+        d["region"] = ("first fw_render_scene call of a fresh process after fw_init: ms_wall = scene + render + D2H; before it ms_import_torch (the Python host's own plumbing), ms_library_load (dlopen: no HIP call since "
                        "ABI v7) and ms_fw_init (HIP context, code objects, kernel handles, staging, the default path arena: 0.4 ms to 1.4 s by the state of the "
                        "device's memory); ms_cold_total = all three; then the first calls of two other configs in the same process")
         try:
             lazy = child(False)
-            d["without_fw_init"] = {k: lazy[k] for k in ("ms_wall", "ms_library_load", "ms_cold_total", "ms_render", "ms_scene", "trace")}
+            d["without_fw_init"] = {k: lazy[k] for k in ("ms_wall", "ms_import_torch", "ms_library_load", "ms_cold_total", "ms_render", "ms_scene", "trace")}
             d["without_fw_init"]["region"] = "the same first call in a process that never calls fw_init: the call initialises the device itself and sizes the arena for this frame"
         except Exception as e:
             d["without_fw_init"] = {"error": repr(e)}
@@ -496,16 +497,21 @@ def cpu_baseline(args, s, cores):
     from firework_amd import scenes
     from firework_amd._abi import FW_RNG_LCG
     from oracle import oracle_binding as ob       # CPU oracle: the checker, timed as the reported baseline
-    # bounded sample: ~15 s of CPU work at ~0.55 Msamples/s per core on this scene, split between the two builds below
-    cpu_spp = args.cpu_spp or max(16, min(s["samples"], int(15.0 * 0.55e6 * cores / (s["width"] * s["height"]))))
     native = ob.native_timing_build()             # the same source at -O3 -march=native, built on this host: timed only, never the checker
+    # bounded sample: ~16 s of CPU work split between the two builds below, sized by a one-sample pilot (part2 costs 30 x cornell per sample)
+    if args.cpu_spp:
+        cpu_spp = args.cpu_spp
+    else:
+        pscene, pr = scenes.config(args.config, args.width, args.height, 1)
+        p0 = time.perf_counter(); ob.render(pscene, pr, rng_mode=FW_RNG_LCG, n_threads=cores); pdt = max(1e-3, time.perf_counter() - p0)
+        cpu_spp = max(2, min(s["samples"], int(16.0 / pdt)))
     def timed(spp, timing_lib=None):
         cscene, cr = scenes.config(args.config, args.width, args.height, spp)
         c0 = time.perf_counter()
         cres = ob.render(cscene, cr, rng_mode=FW_RNG_LCG, n_threads=cores, timing_lib=timing_lib)   # reference semantics: per-pixel sequential LCG
         cdt = time.perf_counter() - c0
         return cres, cr, cdt
-    half = max(8, cpu_spp // 2) if native else cpu_spp
+    half = max(1, cpu_spp // 2) if native else cpu_spp
     cres, cr, cdt = timed(half)
     out = {"value": cres.stats["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
            "msamples_per_s": cres.stats["samples"] / cdt / 1e6,
@@ -541,9 +547,18 @@ def parity(args, tr, renderer, scene, frame_u8, cpu, cores):
     t0 = time.perf_counter()
     c = ob.render(scene, renderer, pixel_ids=ids, n_threads=cores)
     dt = time.perf_counter() - t0
-    rms = float(np.sqrt(np.mean((g.gamma.astype(np.float64) - c.gamma) ** 2)))
-    rms_lin = float(np.sqrt(np.mean((g.linear.astype(np.float64) - c.linear) ** 2)))
-    return {"rms_gamma": rms, "rms_linear": rms_lin, "gate": 1e-3, "pass": bool(rms <= 1e-3),
+    def rms_of(a, b):
+        # a value that is not a number on BOTH sides counts as equal (part2's turbulence texture has negative albedos: powf of a negative mean is
+        # NaN in the reference, the oracle and on the device alike); on one side only it counts as a difference of 1
+        a = a.astype(np.float64); b = b.astype(np.float64)
+        both = np.isnan(a) & np.isnan(b)
+        one = np.isnan(a) ^ np.isnan(b)
+        d = np.where(both, 0.0, np.where(one, 1.0, np.nan_to_num(a) - np.nan_to_num(b)))
+        return float(np.sqrt(np.mean(d ** 2))), int(both.sum()), int(one.sum())
+    rms, nan_both, nan_one = rms_of(g.gamma, c.gamma)
+    rms_lin = rms_of(g.linear, c.linear)[0]
+    return {"rms_gamma": rms, "rms_linear": rms_lin, "gate": 1e-3, "pass": bool(rms <= 1e-3 and nan_one == 0),
+            "nan_values_on_both_sides": nan_both, "nan_values_on_one_side": nan_one,
             "u8_diffs": int((g.rgb8 != c.rgb8).sum()), "u8_values": int(c.rgb8.size),
             "rays_equal": bool(g.stats["rays"] == c.stats["rays"]), "rays_gpu": int(g.stats["rays"]), "rays_oracle": int(c.stats["rays"]),
             "timed_frame_equals_checked_frame": bool(np.array_equal(frame_u8[ids], g.rgb8)),

@@ -398,6 +398,9 @@ __shared__ float g_ts[8 * 64];
 #ifndef FW_XCD_SWIZZLE
 #define FW_XCD_SWIZZLE 1
 #endif
+#ifndef FW_XCD_MIN
+#define FW_XCD_MIN 8192u        // queues from which a launch takes the XCD-contiguous assignment
+#endif
 // Which queue a single-wave workgroup takes.  Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b mod 8), so with w = b the
 // waves resident on one XCD own every 8th queue — eight XCDs' address translation and L2s all working on the same stretch of every path
 // array.  Round 5: XCD x takes the contiguous eighth [x n/8, (x+1) n/8) of the queues instead, so the windows its waves stream are
@@ -406,10 +409,12 @@ __shared__ float g_ts[8 * 64];
 // gain 1-1.5 % and cornell's runs scatter by more than the difference.  Any bijection is correct: queues are private.
 __device__ __forceinline__ uint32_t wave_index() {
 #if FW_XCD_SWIZZLE
-    // (big launches only: with a few hundred queues per XCD a contiguous eighth is a contiguous piece of the IMAGE, and one XCD gets the
-    // expensive pixels — random_spheres, 5 600 queues: 1.65 -> 1.77 ms, profiles/r05e_xcd_ab.txt)
+    // (not for small launches: with a few hundred queues per XCD a contiguous eighth is a contiguous piece of the IMAGE, and one XCD gets the
+    // expensive pixels — random_spheres, 5 600 queues: 1.65 -> 1.72-1.77 ms, profiles/r05e_xcd_ab.txt, r05g_share_xcd.txt.  From 8 192 queues
+    // on it pays most where batches are short: rank 0's share of a 4-rank cornell frame, 12 288 queues, 10.05 -> 8.82 ms = 79 -> 95 % of
+    // ideal; of an 8-rank frame 4.73 -> 4.50 ms = 84 -> 94 %: its k_extend_linear_defer 8.2 -> 6.5 ms)
     const uint32_t per = gridDim.x >> 3;
-    if ((gridDim.x & 7u) == 0u && gridDim.x >= 16384u) return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((gridDim.x & 7u) == 0u && gridDim.x >= FW_XCD_MIN) return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 #endif
     return blockIdx.x * (WB / 64) + (threadIdx.x >> 6);
 }
@@ -2266,10 +2271,25 @@ template <int FMT> __device__ __forceinline__ WideSel wide_sel(V3 inv) {
     else { s.q[0] = nx ? 1u : 0u; s.q[1] = ny ? 1u : 0u; s.q[2] = nz ? 1u : 0u; }
     return s;
 }
+#ifndef FW_WIDE_FMA
+#define FW_WIDE_FMA 1
+#endif
+// FW_WIDE_FMA (round 5): a plane's distance as ONE fma — fma(plane, 1/d, -o/d) instead of (plane - o) * (1/d), and for quantised nodes
+// fma(q, 2^e/d, (origin - o)/d) instead of decoding the plane first: 33 instead of 51 vector instructions for the four boxes of an f32
+// step, 66 instead of 99 for a quantised one, in kernels that issue vector instructions 0.9 of the time.  The distances differ from the
+// subtract-first form by ~2^-24 |o/d| (absolute) — the ulp of the origin's coordinate, orders of magnitude below what the walked boxes are
+// relaxed by (hit_aabb_entry: exit planes x (1 + 2^-12), boxes grown by >= 2^-14 of their extent on the host) — and the walked boxes decide
+// nothing: which item wins is decided by the exact item tests, the reference-rank rule and the reference's own box test on its leaf node's
+// box (tri_gate_ok / obj_gate_ok).  Where a direction component is 0 the fma form meets inf - inf = NaN, which fmaxf / fminf drop: that axis
+// then constrains nothing (conservative: a few more visits for axis-parallel rays).
 template <int FMT>
 __device__ __forceinline__ uint32_t wide_step(const uint32_t *__restrict__ nodes, uint32_t node, V3 o, V3 inv, V3 inv_hi, const WideSel &sel,
                                               float tmin, float tmax, float cull, LdsStackW &st) {
     float4 NX, NY, NZ, FX, FY, FZ; uint32_t r01, r23;
+#if FW_WIDE_FMA
+    V3 mn = inv, mf = inv_hi;                                            // multipliers and addends of the near / far planes' fma
+    V3 an = mk(-o.x * inv.x, -o.y * inv.y, -o.z * inv.z), af = mk(-o.x * inv_hi.x, -o.y * inv_hi.y, -o.z * inv_hi.z);
+#endif
     if (FMT == WIDE_F32) {
         const char *nd = reinterpret_cast<const char *>(nodes) + __umul24(node, WIDE_F32_DW * 4u);     // node < 2^15: the 24-bit multiply is full rate
         NX = *reinterpret_cast<const float4 *>(nd + sel.q[0]); NY = *reinterpret_cast<const float4 *>(nd + sel.q[1]); NZ = *reinterpret_cast<const float4 *>(nd + sel.q[2]);
@@ -2284,10 +2304,19 @@ __device__ __forceinline__ uint32_t wide_step(const uint32_t *__restrict__ nodes
         const uint32_t nxw = sel.q[0] ? hi.x : lo.x, fxw = sel.q[0] ? lo.x : hi.x, nyw = sel.q[1] ? hi.y : lo.y, fyw = sel.q[1] ? lo.y : hi.y,
                        nzw = sel.q[2] ? hi.z : lo.z, fzw = sel.q[2] ? lo.z : hi.z;
         // plane = fma(q, 2^e, origin): q * 2^e is exact, so this is the one rounding the host checked its outward rounding with
+#if FW_WIDE_FMA
+        // the quanta themselves stand in for the planes: distance = fma(q, 2^e / d, (origin - o) / d)
+        auto qf = [](uint32_t w) { return make_float4((float)(w & 0xffu), (float)((w >> 8) & 0xffu), (float)((w >> 16) & 0xffu), (float)(w >> 24)); };
+        NX = qf(nxw); NY = qf(nyw); NZ = qf(nzw); FX = qf(fxw); FY = qf(fyw); FZ = qf(fzw);
+        const V3 rel = mk(ox - o.x, oy - o.y, oz - o.z);
+        an = mk(rel.x * inv.x, rel.y * inv.y, rel.z * inv.z); af = mk(rel.x * inv_hi.x, rel.y * inv_hi.y, rel.z * inv_hi.z);
+        mn = mk(sx * inv.x, sy * inv.y, sz * inv.z); mf = mk(sx * inv_hi.x, sy * inv_hi.y, sz * inv_hi.z);
+#else
         auto dq = [](uint32_t w, float s, float org) {
             return make_float4(fmaf((float)(w & 0xffu), s, org), fmaf((float)((w >> 8) & 0xffu), s, org), fmaf((float)((w >> 16) & 0xffu), s, org), fmaf((float)(w >> 24), s, org));
         };
         NX = dq(nxw, sx, ox); NY = dq(nyw, sy, oy); NZ = dq(nzw, sz, oz); FX = dq(fxw, sx, ox); FY = dq(fyw, sy, oy); FZ = dq(fzw, sz, oz);
+#endif
         r01 = lo.w; r23 = hi.w;
     }
     const uint32_t NONE = 0xffffffffu;
@@ -2295,8 +2324,13 @@ __device__ __forceinline__ uint32_t wide_step(const uint32_t *__restrict__ nodes
     // like unsigned integers).  key = upper half of the entry | reference; a child that fails gets NONE, which sorts last and whose
     // low half reads W_DONE.
     auto key = [&](float nx, float ny, float nz, float fx, float fy, float fz, uint32_t ref16) -> uint32_t {
+#if FW_WIDE_FMA
+        const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(nx, mn.x, an.x), __builtin_fmaf(ny, mn.y, an.y)), __builtin_fmaf(nz, mn.z, an.z)), tmin);
+        const float tf = fminf(fminf(fminf(__builtin_fmaf(fx, mf.x, af.x), __builtin_fmaf(fy, mf.y, af.y)), __builtin_fmaf(fz, mf.z, af.z)), tmax);   // relaxed exit (hit_aabb_entry)
+#else
         const float tn = fmaxf(fmaxf(fmaxf((nx - o.x) * inv.x, (ny - o.y) * inv.y), (nz - o.z) * inv.z), tmin);
         const float tf = fminf(fminf(fminf((fx - o.x) * inv_hi.x, (fy - o.y) * inv_hi.y), (fz - o.z) * inv_hi.z), tmax);   // relaxed exit (hit_aabb_entry)
+#endif
         const bool hit = tf > tn && !(tn > cull);
         return hit ? ((__float_as_uint(tn) & 0xffff0000u) | ref16) : NONE;
     };

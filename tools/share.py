@@ -19,6 +19,8 @@ for world in [int(x) for x in os.environ.get("SHARE_WORLDS", "1,2,4,8").split(",
     for _ in range(n): tr.render_frame()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3 / n
     st = tr.last_stats
-    base = base or ms
-    print(f"world {world}: {ms:7.2f} ms/frame wall, device {st['ms_render']:.2f} ms, ideal {base / world:.2f} ms, efficiency {base / world / ms:.2%} ext {st['ms_extend']:.2f} shd {st['ms_shade']:.2f} rg {st['ms_raygen']:.2f} acc {st['ms_accumulate']:.2f} batches {st['n_batches']}", flush=True)
+    if world == 1:
+        base = ms
+    eff = f"ideal {base / world:.2f} ms, efficiency {base / world / ms:.2%}" if base else "ideal n/a (run world 1 first: SHARE_WORLDS=1,...)"
+    print(f"world {world}: {ms:7.2f} ms/frame wall, device {st['ms_render']:.2f} ms, {eff} ext {st['ms_extend']:.2f} shd {st['ms_shade']:.2f} rg {st['ms_raygen']:.2f} acc {st['ms_accumulate']:.2f} batches {st['n_batches']}", flush=True)
     tr.close()
