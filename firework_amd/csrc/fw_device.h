@@ -223,6 +223,8 @@ struct LaunchCfg {
     uint32_t n_mat, n_tex;        // table sizes (for the LDS-resident copy in k_shade)
     bool lds_tables;              // stage small scene tables in LDS (debug switch: FIREWORK_NO_LDS_TABLES)
     bool has_mesh;
+    bool simple_but_meshes;   // ... where meshes do not count (k_extend_scan parks them): suzanne, teapot
+    bool simple_set;      // every object is a sphere, an axis-aligned rectangle, a Rect3d, or a medium around a sphere: kernels with hit_shape's SIMPLE form (round 5)
     int n_cus;
     uint32_t blas_pair_nodes, tlas_pair_nodes, max_tris, n_tris;   // n_tris: all meshes together
     bool no_lds_tris;     // A/B switch FIREWORK_NO_LDS_TRIS   // sizes of the walked trees (pair nodes) and of the biggest mesh

@@ -1057,10 +1057,19 @@ __device__ __forceinline__ bool hit_mesh_exact_wave(const DScene &sc, uint32_t r
 
 // shape dispatch in object space.  prim: rect3d face / mesh triangle, else 0.  EXACT: a mesh takes the literal reference walk
 // and aux0 is its reference tree's first node (k_extend_exact; 1: one ray per lane, 2: per wave).
-template <int EXACT = 0, bool MESH = true>
+// SIMPLE (round 5): the caller's scene holds spheres, axis-aligned rectangles and Rect3d boxes only, plus media whose inner shape is a sphere
+// (LaunchCfg.simple_set: the host checks) — the other six shapes' code is compiled out of the caller (part2's k_extend_tlas_wide: 143 KB of
+// code against a 64 KB instruction cache; a medium's two boundary tests each inlined the whole dispatch)
+template <int EXACT = 0, bool MESH = true, bool SIMPLE = false>
 __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float4 q3, float4 q4, uint32_t aux0, uint32_t aux1,
                                           const Ray &r, float tmin, float tmax, uint32_t *stack_base, float &t, uint32_t &prim) {
     prim = 0;
+    if (SIMPLE) {
+        if (kind == 0u) return hit_sphere(q3.x, r, tmin, tmax, t);
+        if (kind == 4u) return hit_rect3d(q3, q4, r, tmin, tmax, t, prim);
+        if (kind >= 1u && kind <= 3u) return hit_rect_kind(kind, q3, q4, r, tmin, tmax, t);
+        return false;
+    }
     if (!MESH && kind == 5u) return false;     // the caller's scene holds no mesh (the host checks): the walk is compiled out
     switch (kind) {
     case 0: return hit_sphere(q3.x, r, tmin, tmax, t);
@@ -1077,15 +1086,20 @@ __device__ __forceinline__ bool hit_shape(const DScene &sc, uint32_t kind, float
 }
 
 // objects/volume.rs:56-82
-template <int EXACT = 0, bool MESH = true>
+template <int EXACT = 0, bool MESH = true, bool SIMPLE = false>
 __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const Ray &r, float tmin, float tmax,
                                            uint32_t *stack_base, const RngKey &key, uint32_t segment, uint32_t obj_index, float &t_out) {
     const float FMAX = 3.40282347e+38f;
     uint32_t ik = obj_inner(o), prim;
     float t1, t2;
     const uint32_t root = EXACT ? sc.obj_ref_blas[obj_index] : o.aux0;
+    if (SIMPLE) {       // the inner shape is a sphere (the host checks): the same two calls of volume.rs:58-61, without the dispatch
+        if (!hit_sphere(o.q3.x, r, -FMAX, FMAX, t1)) return false;
+        if (!hit_sphere(o.q3.x, r, t1 + 0.0001f, FMAX, t2)) return false;
+    } else {
     if (!hit_shape<EXACT, MESH>(sc, ik, o.q3, o.q4, root, o.aux1, r, -FMAX, FMAX, stack_base, t1, prim)) return false;
     if (!hit_shape<EXACT, MESH>(sc, ik, o.q3, o.q4, root, o.aux1, r, t1 + 0.0001f, FMAX, stack_base, t2, prim)) return false;
+    }
     t1 = fmaxf(t1, tmin);
     t2 = fminf(t2, tmax);
     if (t1 >= t2) return false;
@@ -1101,14 +1115,14 @@ __device__ __forceinline__ bool hit_medium(const DScene &sc, const Obj &o, const
 // RenderObjectInternal::hit up to the object-space t (the world-space point/normal are rebuilt in k_shade)
 // MEDIUM = false: the caller's scene holds no ConstantMedium (k_extend_linear_defer: the host checks), so the medium's code —
 // its double-precision log10 costs registers even where it never runs — is compiled out; MESH = false likewise for the mesh walk
-template <bool MEDIUM = true, int EXACT = 0, bool MESH = true>
+template <bool MEDIUM = true, int EXACT = 0, bool MESH = true, bool SIMPLE = false>
 __device__ __forceinline__ bool hit_object(const DScene &sc, const Obj &o, uint32_t obj_index, const Ray &world, float tmin,
                                            float tmax, uint32_t *stack_base, const RngKey &key, uint32_t segment, float &t, uint32_t &prim) {
     Ray r = to_object_space(o, world);
     uint32_t kind = obj_kind(o);
-    if (MEDIUM && kind == 6) { prim = 0; return hit_medium<EXACT, MESH>(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
+    if (MEDIUM && kind == 6) { prim = 0; return hit_medium<EXACT, MESH, SIMPLE>(sc, o, r, tmin, tmax, stack_base, key, segment, obj_index, t); }
     const uint32_t root = (EXACT && kind == 5u) ? sc.obj_ref_blas[obj_index] : o.aux0;
-    return hit_shape<EXACT, MESH>(sc, kind, o.q3, o.q4, root, o.aux1, r, tmin, tmax, stack_base, t, prim);
+    return hit_shape<EXACT, MESH, SIMPLE>(sc, kind, o.q3, o.q4, root, o.aux1, r, tmin, tmax, stack_base, t, prim);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1240,6 +1254,7 @@ struct BlockStream {
 // their leaf would: the object's leaf box first (obj_leaf = its box in the walked tree: that of its reference leaf node), the gate box where it has one,
 // then the object with the caller's [TMIN, TMAX], ties by reference rank.  A walk that starts from this result culls
 // against its t like against any other hit.
+template <bool SIMPLE = false>
 __device__ __forceinline__ void hoisted_hits(const DScene &sc, const Ray &r, V3 inv, const RngKey &key, int segment, uint32_t *blas_stack,
                                              bool &have, float &best_t, uint32_t &best_obj, uint32_t &best_prim) {
     const float TMIN = 0.001f, TMAX = 2e9f;                          // render.rs:19
@@ -1249,7 +1264,7 @@ __device__ __forceinline__ void hoisted_hits(const DScene &sc, const Ray &r, V3 
         if (!hit_aabb_entry(sc.obj_leaf[2 * (size_t)k], sc.obj_leaf[2 * (size_t)k + 1], r.o, inv, relaxed(inv), box_tmin(TMIN, false), TMAX, entry)) continue;
         Obj o = load_obj(sc.obj, k);
         float t; uint32_t prim;
-        if (hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+        if (SIMPLE ? hit_object<true, 0, false, true>(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim) : hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
             if ((!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, k, r.o, inv)) { have = true; best_t = t; best_obj = k; best_prim = prim; }
         }
     }
@@ -1261,7 +1276,7 @@ __device__ __forceinline__ void hoisted_hits(const DScene &sc, const Ray &r, V3 
 // bound by instruction issue and whose code then fits the instruction cache (k_extend_linear: 93 KB with it)
 // MEDIUM = false likewise for a scene without a ConstantMedium (its two boundary tests and double-precision log10): hdri's scan is then
 // a quarter of the code and keeps its registers
-template <bool USE_BVH, bool DEFER, bool MESH = true, bool MEDIUM = true>
+template <bool USE_BVH, bool DEFER, bool MESH = true, bool MEDIUM = true, bool SIMPLE = false>
 __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, const RngKey &key, int segment,
                                             uint32_t *my_stack, uint32_t *blas_stack, float &best_t, uint32_t &best_obj,
                                             uint32_t &best_prim, bool &deferred, uint32_t &deferred_obj, bool soft = false) {
@@ -1296,7 +1311,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
                     if (__ballot(maybe) == 0ull) continue;
                 }
                 float t; uint32_t prim;
-                if (hit_object<MEDIUM, 0, MESH>(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+                if (hit_object<MEDIUM, 0, MESH, SIMPLE>(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
             }
         } else {
             // the loop of all later segments: no pre-test, nothing but the scan (the scalar unit is as busy as the VALUs here)
@@ -1304,7 +1319,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
             for (uint32_t k = 0; k < sc.n_objects; k++, op += OBJ_Q) {
                 Obj o = load_obj(op, 0);
                 float t; uint32_t prim;
-                if (hit_object<MEDIUM, 0, MESH>(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
+                if (hit_object<MEDIUM, 0, MESH, SIMPLE>(sc, o, k, r, TMIN, best_t, blas_stack, key, segment, t, prim)) { best_t = t; best_obj = k; best_prim = prim; }
             }
         }
     } else {
@@ -1349,7 +1364,7 @@ __device__ __forceinline__ void closest_hit(const DScene &sc, const Ray &r, cons
     }
 }
 
-template <bool USE_BVH, bool REFILL, bool PARK, bool MESH = true, bool MEDIUM = true>
+template <bool USE_BVH, bool REFILL, bool PARK, bool MESH = true, bool MEDIUM = true, bool SIMPLE = false>
 __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, const DPaths &in, float2 *__restrict__ hits,
                                             const DQueue &q, int segment, int tlas_levels, int stack_levels, const DPark &park) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
@@ -1566,7 +1581,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
             RngKey key{0, 0, 0};
             if (sc.has_medium) key = key_of(f, __float_as_uint(load_home(in, i, f, segment)));
             if (!skip_ray(f.ex, r))     // a NaN ray's record comes from k_extend_exact
-                closest_hit<USE_BVH, USE_BVH, MESH, MEDIUM>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj,
+                closest_hit<USE_BVH, USE_BVH, MESH, MEDIUM, SIMPLE>(sc, r, key, segment, my_stack, blas_stack, best_t, best_obj, best_prim, deferred, deferred_obj,
                                               USE_BVH && sc.has_mesh && soft_ray(f.ex, r.d, sc.soft_shear));
             if (!USE_BVH && f.hit4) reinterpret_cast<uint32_t *>(hits)[i] = __float_as_uint(pack_hit(best_t, best_obj, best_prim, sc.prim_bits).y);   // the code alone: k_shade recomputes t
             else if (!deferred) qst(&hits[i], pack_hit(best_t, best_obj, best_prim, sc.prim_bits));
@@ -1606,7 +1621,7 @@ __device__ __forceinline__ void extend_body(const DScene &sc, const DFrame &f, c
 #endif
 // PLAIN: the scene holds no ConstantMedium (the host checks) — meshes are parked, never walked here, so without a medium neither the mesh
 // walk nor the medium's code is needed: compiled out (53 KB of code and 11 spilled registers with them)
-template <bool PARK, bool PLAIN = false>
+template <bool PARK, bool PLAIN = false, bool SIMPLE = false>     // SIMPLE (with PLAIN): whatever is not a mesh is a sphere, a rectangle or a box (suzanne, teapot)
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(PLAIN ? FW_SCAN_WAVES_PLAIN : FW_SCAN_WAVES, 8))) void k_extend_scan(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment,
                                                     int tlas_levels, float4 *__restrict__ park_a, float2 *__restrict__ park_b, float4 *__restrict__ park_m,
                                                     uint32_t *__restrict__ park_count, uint32_t park_stride) {
@@ -1651,7 +1666,7 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(PLAIN ? FW_S
                     continue;                                                                            // parked, the others were walked here, in place, from L2)
                 }
                 float t; uint32_t prim;
-                if (PLAIN ? hit_object<false, 0, false>(sc, o, k, r, TMIN, TMAX, nullptr, key, segment, t, prim) : hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
+                if (PLAIN ? hit_object<false, 0, false, SIMPLE>(sc, o, k, r, TMIN, TMAX, nullptr, key, segment, t, prim) : hit_object(sc, o, k, r, TMIN, TMAX, blas_stack, key, segment, t, prim)) {
                     if ((!have || t < best_t || (t == best_t && sc.obj_rank[k] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, k, r.o, inv)) { have = true; best_t = t; best_obj = k; best_prim = prim; }
                 }
             }
@@ -1699,6 +1714,7 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(PLAIN ? FW_S
 // has 65 - (one chunk's candidates) to 64 of its lanes busy instead of all of them.
 constexpr uint32_t DEFER_FIELDS = 9;       // slot | later-list bit 31, t, code, origin.xyz, direction.xyz — [field][64] per list
 extern __shared__ uint32_t lds_defer[];
+template <bool SIMPLE>      // the objects in front of the listed boxes are spheres / rectangles / boxes only (cornell): hit_shape's SIMPLE form
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(FW_DEFER_WAVES, 8)))
 void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, uint32_t n_def) {
     const uint32_t w = wave_index(), lane = threadIdx.x & 63u;
@@ -1792,7 +1808,7 @@ void k_extend_linear_defer(DScene sc, DFrame f, DPaths in, float2 *__restrict__ 
                     if (kind == 1u) h = hit_rect_rcp<0>(o.q3.x, o.q3.y, o.q3.z, o.q3.w, o.q4.x, ro, rcz, TMIN, best_t, t);
                     else if (kind == 2u) h = hit_rect_rcp<1>(o.q3.x, o.q3.y, o.q3.z, o.q3.w, o.q4.x, ro, rcy, TMIN, best_t, t);
                     else h = hit_rect_rcp<2>(o.q3.x, o.q3.y, o.q3.z, o.q3.w, o.q4.x, ro, rcx, TMIN, best_t, t);
-                } else h = hit_object<false, 0, false>(sc, o, k, r, TMIN, best_t, nullptr, nokey, segment, t, prim);
+                } else h = hit_object<false, 0, false, SIMPLE>(sc, o, k, r, TMIN, best_t, nullptr, nokey, segment, t, prim);
                 if (h) { best_t = t; best_obj = k; best_prim = prim; }
             }
             // conservative pre-tests (see closest_hit's segment-0 cull: approximate reciprocals, boxes inflated by 1e-4 of the
@@ -1847,6 +1863,12 @@ void k_extend_linear_nomesh(DScene sc, DFrame f, DPaths in, float2 *__restrict__
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(7, 8)))
 void k_extend_linear_plain(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
     extend_body<false, false, false, false, false>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
+}
+// round 5: the SIMPLE set (hit_shape): spheres, rectangles, boxes, and media around spheres — hdri (no medium) and volume (one)
+template <bool MEDIUM>
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(7, 8)))
+void k_extend_linear_simple(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q, int segment, int tlas_levels, int stack_levels) {
+    extend_body<false, false, false, false, MEDIUM, true>(sc, f, in, hits, q, segment, tlas_levels, stack_levels, DPark{});
 }
 #if FW_AB
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(5, 8)))
@@ -2320,9 +2342,12 @@ __device__ __forceinline__ uint32_t wide_step(const uint32_t *__restrict__ nodes
         r01 = lo.w; r23 = hi.w;
     }
     const uint32_t NONE = 0xffffffffu;
-    // hit_aabb_entry on one child with the planes already chosen; entry clamped to tmin (> 0 here: the bits of a positive float order
-    // like unsigned integers).  key = upper half of the entry | reference; a child that fails gets NONE, which sorts last and whose
-    // low half reads W_DONE.
+    // hit_aabb_entry on one child with the planes already chosen; entry clamped to tmin.  key = upper half of the entry | reference; a child
+    // that fails gets NONE, which sorts last and whose low half reads W_DONE.  The bits of a POSITIVE float order like unsigned integers, and
+    // tmin > 0 for every ray but the SOFT class (box_tmin: -1/16, boxes entered from behind the origin), whose negative entries sort behind
+    // the positive ones and among themselves in reverse.  That is harmless because — and only as long as — a SOFT ray walks with NO_CULL: it
+    // visits every child that passes whatever the order, and the order of visits decides no hit (ties go by reference rank).  A change that
+    // lets SOFT rays cull must build the key from fmaxf(tn, 0) (one more instruction per child) or flip the sign bit.
     auto key = [&](float nx, float ny, float nz, float fx, float fy, float fz, uint32_t ref16) -> uint32_t {
 #if FW_WIDE_FMA
         const float tn = fmaxf(fmaxf(fmaxf(__builtin_fmaf(nx, mn.x, an.x), __builtin_fmaf(ny, mn.y, an.y)), __builtin_fmaf(nz, mn.z, an.z)), tmin);
@@ -2501,7 +2526,8 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) __attribute__((amdgpu_waves_pe
 }
 
 // k_extend_tlas_lds over WIDE_F32 nodes (scenes without meshes: part2's TLAS, random_spheres)
-template <bool MEDIUM>      // false: the scene holds no ConstantMedium (random_spheres): its code — two boundary tests and a double-precision log10 — compiled out
+template <bool MEDIUM, bool SIMPLE = false>      // MEDIUM false: the scene holds no ConstantMedium (random_spheres): its code — two boundary tests and a log10 — compiled out;
+                                                  // SIMPLE: spheres, rectangles, boxes and media around spheres only (part2): hit_shape's SIMPLE form
 __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene sc, DFrame f, DPaths in, float2 *__restrict__ hits, DQueue q,
                                                                           int segment, uint32_t n_nodes, uint32_t levels) {
     extern __shared__ uint32_t lds_w[];
@@ -2538,7 +2564,7 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene
                 RngKey hkey{0, 0, 0};
                 if (sc.has_medium) hkey = key_of(f, __float_as_uint(cs));
                 bool hv = false;
-                hoisted_hits(sc, r, iv, hkey, segment, nullptr, hv, h_t, h_obj, h_prim);
+                hoisted_hits<SIMPLE>(sc, r, iv, hkey, segment, nullptr, hv, h_t, h_obj, h_prim);
             }
         }
     };
@@ -2608,7 +2634,8 @@ __global__ __launch_bounds__(WIDE_MAX_WAVES * 64) void k_extend_tlas_wide(DScene
             if (sc.has_medium) key = key_of(f, path_id);
             float t; uint32_t prim;
             // (with a medium the generic test stays: compiling the mesh walk out of the medium's boundary tests alone made part2 1 % slower, 82.6 -> 83.4 ms)
-            if (hit_object<MEDIUM, 0, MEDIUM>(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)) {
+            if (SIMPLE ? hit_object<MEDIUM, 0, false, true>(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)
+                       : hit_object<MEDIUM, 0, MEDIUM>(sc, o, item, Ray{wo, wd}, TMIN, TMAX, nullptr, key, segment, t, prim)) {
                 if ((!have || t < best_t || (t == best_t && sc.obj_rank[item] > sc.obj_rank[best_obj])) && obj_gate_ok(sc, item, wo, inv)) { have = true; best_t = t; best_obj = item; best_prim = prim; }
             }
             PH_ADD(3);
@@ -3692,7 +3719,8 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
     auto walk_grid = [&](uint32_t waves) { return std::min<uint32_t>((uint32_t)c.n_cus, (c.q.n_waves + waves - 1) / waves); };
     if (use_bvh && c.tlas_refill && c.has_mesh) {
         // TLAS walk that parks mesh rays in HBM, then their BLAS walks; a medium around a mesh still walks it in place (blas levels)
-        if (sc.n_objects <= TLAS_SCAN_MAX && !sc.has_medium) hipLaunchKernelGGL((k_extend_scan<true, true>), eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park.ray_a, park.ray_b, park.meta, park.pcount, park.stride);
+        if (sc.n_objects <= TLAS_SCAN_MAX && !sc.has_medium && c.simple_but_meshes) hipLaunchKernelGGL((k_extend_scan<true, true, true>), eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park.ray_a, park.ray_b, park.meta, park.pcount, park.stride);
+        else if (sc.n_objects <= TLAS_SCAN_MAX && !sc.has_medium) hipLaunchKernelGGL((k_extend_scan<true, true>), eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park.ray_a, park.ray_b, park.meta, park.pcount, park.stride);
         else if (sc.n_objects <= TLAS_SCAN_MAX) hipLaunchKernelGGL(k_extend_scan<true>, eg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, park.ray_a, park.ray_b, park.meta, park.pcount, park.stride);
         else hipLaunchKernelGGL(k_extend_tlas_park, sg, dim3(WB), (size_t)levels * WB * sizeof(uint32_t), c.stream, sc, f, in, hits, c.q, segment, tl, levels, park);
         // The parked rays' BLAS walks.  WIDE nodes out of LDS where the scene has them (f32, or quantised for a BLAS too big for those):
@@ -3746,9 +3774,13 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
                 if (lds_attr_needed(3)) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
                     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_extend_tlas_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>((k_extend_tlas_wide<true, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>((k_extend_tlas_wide<false, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_TREE_LIMIT);
                 }
                 const dim3 lg(walk_grid(waves));
-                if (sc.has_medium) hipLaunchKernelGGL(k_extend_tlas_wide<true>, lg, dim3(waves * 64), lds_walk_bytes(tree, waves, wl, c.q.n_waves, lg.x), c.stream, sc, f, in, hits, c.q, segment, c.wtlas_nodes, wl);
+                if (!sc.has_medium && c.simple_set) hipLaunchKernelGGL((k_extend_tlas_wide<false, true>), lg, dim3(waves * 64), lds_walk_bytes(tree, waves, wl, c.q.n_waves, lg.x), c.stream, sc, f, in, hits, c.q, segment, c.wtlas_nodes, wl);
+                else if (sc.has_medium && c.simple_set) hipLaunchKernelGGL((k_extend_tlas_wide<true, true>), lg, dim3(waves * 64), lds_walk_bytes(tree, waves, wl, c.q.n_waves, lg.x), c.stream, sc, f, in, hits, c.q, segment, c.wtlas_nodes, wl);
+                else if (sc.has_medium) hipLaunchKernelGGL(k_extend_tlas_wide<true>, lg, dim3(waves * 64), lds_walk_bytes(tree, waves, wl, c.q.n_waves, lg.x), c.stream, sc, f, in, hits, c.q, segment, c.wtlas_nodes, wl);
                 else hipLaunchKernelGGL(k_extend_tlas_wide<false>, lg, dim3(waves * 64), lds_walk_bytes(tree, waves, wl, c.q.n_waves, lg.x), c.stream, sc, f, in, hits, c.q, segment, c.wtlas_nodes, wl);
                 return;
             }
@@ -3765,7 +3797,10 @@ void launch_extend(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
 #if FW_AB
     else if (use_bvh) hipLaunchKernelGGL(k_extend_bvh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
 #endif
-    else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer, eg, dim3(WB), (size_t)2 * 64 * DEFER_FIELDS * 4 + FW_DEFER_LDS_PAD, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
+    else if (c.n_defer && c.simple_set) hipLaunchKernelGGL(k_extend_linear_defer<true>, eg, dim3(WB), (size_t)2 * 64 * DEFER_FIELDS * 4 + FW_DEFER_LDS_PAD, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
+    else if (c.n_defer) hipLaunchKernelGGL(k_extend_linear_defer<false>, eg, dim3(WB), (size_t)2 * 64 * DEFER_FIELDS * 4 + FW_DEFER_LDS_PAD, c.stream, sc, f, in, hits, c.q, segment, c.n_defer);
+    else if (c.simple_set && !sc.has_medium) hipLaunchKernelGGL(k_extend_linear_simple<false>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
+    else if (c.simple_set) hipLaunchKernelGGL(k_extend_linear_simple<true>, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else if (!c.has_mesh && !sc.has_medium) hipLaunchKernelGGL(k_extend_linear_plain, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else if (!c.has_mesh) hipLaunchKernelGGL(k_extend_linear_nomesh, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
     else hipLaunchKernelGGL(k_extend_linear, eg, dim3(WB), lds, c.stream, sc, f, in, hits, c.q, segment, tl, levels);
@@ -3821,10 +3856,10 @@ void launch_bounce(const LaunchCfg &c, const DScene &sc, const DFrame &f, DPaths
 void preload_kernels() {
     hipFuncAttributes a;
 #define FW_TOUCH(k) (void)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(k))
-    FW_TOUCH(k_raygen); FW_TOUCH(k_extend_linear); FW_TOUCH(k_extend_linear_nomesh); FW_TOUCH(k_extend_linear_plain); FW_TOUCH(k_extend_linear_defer); FW_TOUCH(k_extend_scan<true>); FW_TOUCH((k_extend_scan<true, true>)); FW_TOUCH(k_extend_scan<false>);
+    FW_TOUCH(k_raygen); FW_TOUCH(k_extend_linear); FW_TOUCH(k_extend_linear_nomesh); FW_TOUCH(k_extend_linear_plain); FW_TOUCH(k_extend_linear_defer<true>); FW_TOUCH(k_extend_linear_defer<false>); FW_TOUCH(k_extend_linear_simple<true>); FW_TOUCH(k_extend_linear_simple<false>); FW_TOUCH(k_extend_scan<true>); FW_TOUCH((k_extend_scan<true, true>)); FW_TOUCH((k_extend_scan<true, true, true>)); FW_TOUCH(k_extend_scan<false>);
     FW_TOUCH(k_extend_tlas); FW_TOUCH(k_extend_tlas_park); FW_TOUCH(k_blas); FW_TOUCH(k_blas_lds<true>); FW_TOUCH(k_blas_lds<false>); FW_TOUCH(k_extend_tlas_lds);
     FW_TOUCH((k_blas_wide<WIDE_F32, true>)); FW_TOUCH((k_blas_wide<WIDE_F32, false>)); FW_TOUCH((k_blas_wide<WIDE_Q8, true>)); FW_TOUCH((k_blas_wide<WIDE_Q8, false>));
-    FW_TOUCH(k_extend_tlas_wide<true>); FW_TOUCH(k_extend_tlas_wide<false>); FW_TOUCH(k_extend_exact); FW_TOUCH(k_queue_totals); FW_TOUCH(k_count_deposits); FW_TOUCH(k_accumulate); FW_TOUCH(k_tile_order);
+    FW_TOUCH(k_extend_tlas_wide<true>); FW_TOUCH(k_extend_tlas_wide<false>); FW_TOUCH((k_extend_tlas_wide<true, true>)); FW_TOUCH((k_extend_tlas_wide<false, true>)); FW_TOUCH(k_extend_exact); FW_TOUCH(k_queue_totals); FW_TOUCH(k_count_deposits); FW_TOUCH(k_accumulate); FW_TOUCH(k_tile_order);
     FW_TOUCH(k_resolve); FW_TOUCH(k_scatter_tiles);
     FW_TOUCH((k_shade<0, 0, false>)); FW_TOUCH((k_shade<0, 0, true>)); FW_TOUCH((k_shade<0, 1, false>)); FW_TOUCH((k_shade<0, 1, true>));
     FW_TOUCH((k_shade<1, 0, false>)); FW_TOUCH((k_shade<1, 0, true>)); FW_TOUCH((k_shade<1, 1, false>)); FW_TOUCH((k_shade<1, 1, true>));

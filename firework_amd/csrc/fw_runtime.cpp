@@ -855,6 +855,8 @@ struct fw_scene {
     uint32_t wblas_nodes = 0, wtlas_nodes = 0, wblas_depth = 0, wtlas_depth = 0;
     bool has_expensive = false;   // some material is a dielectric or carries a non-constant texture, or the environment is an HDR map (k_shade's list)
     bool simple_shapes = false;   // every object is a sphere, an axis-aligned rect or a Rect3d (no medium, mesh, cone, cylinder, disk)
+    bool simple_set = false;      // ... or a medium around a sphere (LaunchCfg.simple_set)
+    bool simple_but_meshes = false;   // every object is a sphere, a rect, a Rect3d or a TriangleMesh (LaunchCfg.simple_but_meshes)
     bool hdr_env = false;
     fw::DExact ex{};              // flag rule of the exact walk (bits pointer is per render)
     uint32_t ref_tlas_depth = 0, ref_blas_depth = 0;
@@ -1482,7 +1484,13 @@ int create_scene_impl(const fw_scene_desc *desc, int device, fw_scene **out) {
         if (constant && 10u * bits <= 32u) sc->chain_bits = bits;
     }
     sc->simple_shapes = true;
-    for (uint32_t i = 0; i < desc->n_objects; i++) { uint32_t kf; std::memcpy(&kf, &objs[(size_t)i * fw::OBJ_Q * 4 + 3], 4); if ((kf & 0xffu) > 4u) sc->simple_shapes = false; }
+    sc->simple_set = true; sc->simple_but_meshes = true;
+    for (uint32_t i = 0; i < desc->n_objects; i++) {
+        uint32_t kf; std::memcpy(&kf, &objs[(size_t)i * fw::OBJ_Q * 4 + 3], 4);
+        if ((kf & 0xffu) > 4u) sc->simple_shapes = false;
+        if ((kf & 0xffu) > 5u) sc->simple_but_meshes = false;
+        if ((kf & 0xffu) > 4u && !((kf & 0xffu) == FW_SHAPE_CONSTANT_MEDIUM && (kf >> 24) == FW_SHAPE_SPHERE)) sc->simple_set = false;
+    }
     // the trailing plain boxes of a linear scene (k_extend_linear_defer): at most two, no media or meshes anywhere in the scene
     sc->n_defer = 0;
     if (!has_medium && fl.tri.empty())
@@ -1692,6 +1700,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     cfg.n_mat = sc->n_mat; cfg.n_tex = sc->n_tex;
     cfg.lds_tables = !O.no_lds_tables;
     cfg.has_mesh = sc->d.has_mesh != 0;
+    cfg.simple_set = sc->simple_set; cfg.simple_but_meshes = sc->simple_but_meshes;
+#ifdef FW_NO_SIMPLE      // A/B build: the kernels of round 4 (every shape's code in every kernel that calls hit_object)
+    cfg.simple_set = cfg.simple_but_meshes = false;
+#endif
     cfg.tlas_refill = tlas_refill;
     cfg.n_cus = sc->n_cus;
     cfg.blas_pair_nodes = sc->blas_pair_nodes; cfg.tlas_pair_nodes = sc->tlas_pair_nodes; cfg.max_tris = sc->max_tris; cfg.n_tris = sc->n_tris;
