@@ -42,6 +42,7 @@ struct Options {
          no_tile_order = false, no_zero_skip = false, dep_pixel_major = false, dep_slot_major = false, trace = false, no_chain = false,
          exact_product = false;   // EXACT_PRODUCT: textured scenes keep every scattering's attenuation and multiply back to front at deposit (render.rs:23-28's order)
     int streams = 0;              // STREAMS=n batches in flight (0: the library's choice)
+    int phase_lock = -1;          // PHASE_LOCK=0|1: the two batches in flight held in anti-phase, one's extend beside the other's shade (-1: where it pays: box-list scenes)
     int soft_shear_log2 = 5, exact_shear_log2 = 10; double exact_far_x = 256.0;   // SOFT_SHEAR_LOG2 (0: off), EXACT_SHEAR_LOG2, EXACT_FAR_X: the flag rules' thresholds (tools/flag_margin.py)
     double wide_node_cost = 0.0005;   // WIDE_NODE_COST: the constant a wide node costs in the collapse, in root areas (wide_convert)
     int wide = -1;                // WIDE=0|f32|q8: no wide nodes / force an encoding (-1: by size)
@@ -54,7 +55,7 @@ struct Options {
 #endif
 };
 const char *const OPTION_NAMES[] = {"BVH", "NO_EXACT", "EXACT_ALL", "EXACT_FORM", "NO_DEFER", "NO_HIT4", "NO_HOIST", "NO_LDS_TABLES", "NO_LDS_TREES", "NO_LDS_TRIS",
-                                    "NO_SHORT_RAYS", "NO_TILE_ORDER", "NO_ZERO_SKIP", "DEP_PIXEL_MAJOR", "DEP_SLOT_MAJOR", "NO_CHAIN", "EXACT_PRODUCT", "SOFT_SHEAR_LOG2", "EXACT_SHEAR_LOG2", "EXACT_FAR_X", "WIDE_NODE_COST", "TRACE", "STREAMS", "WIDE", "WAVES",
+                                    "NO_SHORT_RAYS", "NO_TILE_ORDER", "NO_ZERO_SKIP", "DEP_PIXEL_MAJOR", "DEP_SLOT_MAJOR", "NO_CHAIN", "EXACT_PRODUCT", "PHASE_LOCK", "SOFT_SHEAR_LOG2", "EXACT_SHEAR_LOG2", "EXACT_FAR_X", "WIDE_NODE_COST", "TRACE", "STREAMS", "WIDE", "WAVES",
                                     "PATHS_PER_BATCH", "DUMP_PATH",
 #if FW_AB
                                     "FUSED", "TLAS_REFILL", "SHADE_LIST", "NO_SHADE_DEFER", "STAGGER", "DEBUG_WIDE_LEVELS",
@@ -81,6 +82,7 @@ bool option_apply(Options &o, const char *name, const char *v) {      // v == nu
     else if (n == "DEP_SLOT_MAJOR") o.dep_slot_major = on();
     else if (n == "NO_CHAIN") o.no_chain = on();
     else if (n == "EXACT_PRODUCT") o.exact_product = v && atoi(v) != 0;
+    else if (n == "PHASE_LOCK") o.phase_lock = v ? (atoi(v) != 0 ? 1 : 0) : -1;
     else if (n == "SOFT_SHEAR_LOG2") o.soft_shear_log2 = v ? (int)num() : 5;
     else if (n == "EXACT_SHEAR_LOG2") o.exact_shear_log2 = v ? (int)num() : 10;
     else if (n == "EXACT_FAR_X") o.exact_far_x = v ? atof(v) : 256.0;
@@ -737,6 +739,7 @@ struct Workspace {
     DevBuf scene_cache;                   // the last destroyed scene's allocation, reused by the next fw_scene_create
     std::vector<hipEvent_t> events;       // [0] frame start, [1] frame stop, [2] fork, [3..] per-batch "accumulated" events
     hipEvent_t ev_d2h = nullptr;          // after the device -> host copies of the outputs
+    std::vector<hipEvent_t> phase_events; // PHASE_LOCK: [lane-in-group][segment] "this batch's extend of the segment has finished"
     DevBuf tile_ids; uint32_t tile_w = 0, tile_h = 0;   // the library's own 16x16-tile pixel order of a (tile_w x tile_h) frame
     void *staging = nullptr; size_t staging_bytes = 0;  // pinned host memory the scene blob is assembled in (k_upload reads it)
     void *host_out = nullptr; size_t host_out_bytes = 0; // pinned host memory the counters and output frames are copied into
@@ -761,6 +764,8 @@ struct Workspace {
         }
         for (hipEvent_t e : events) (void)hipEventDestroy(e);
         events.clear();
+        for (hipEvent_t e : phase_events) (void)hipEventDestroy(e);
+        phase_events.clear();
     }
 };
 constexpr int MAX_DEVICES = 64;
@@ -1572,7 +1577,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // bound by instruction issue, its k_shade by HBM, and they overlap (42.2 -> 40.3 ms in round 2's A/B); per-kernel times for
     // the roofline come from an exclusive pass (FIREWORK_STREAMS=1) that bench.py runs next to the timed loop.
     // (Small frames too: random_spheres, 5.8 M paths, 1.83 ms in two batches against 1.92-1.97 in one, round 3.)
-    int n_lanes = (p->use_bvh || sc->n_defer > 0) ? 2 : 1;
+    // Round 5: two lanes for every scene.  hdri and volume (linear scans without box lists) had lost 1-3 % with two in rounds 2-4; with the
+    // XCD-contiguous queues and the SIMPLE-set scans they gain: hdri 32.4-33.4 -> 31.0-32.0 ms, volume 33.8-36.1 -> 32.4-34.2 (each setting twice in a
+    // row on a box whose processes alternate between two k_shade modes: profiles/r05k_lanes2.txt).
+    int n_lanes = 2;
     if (O.streams >= 1) n_lanes = std::min(O.streams, (int)Workspace::MAX_LANES);
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, p->samples);
     // EXACT_PRODUCT: 160 more bytes per slot (ten attenuation records) where the scene has no chain state: half the default batch
@@ -1781,71 +1789,105 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         HIPCHK(hipEventRecord(ws->events[2], stream));
         for (int l = 0; l < n_lanes; l++) HIPCHK(hipStreamWaitEvent(ws->lanes[l].stream, ws->events[2], 0));
     }
-    for (uint32_t b = 0; b < n_batches; b++) {
+    // The batches of a frame, n_lanes at a time.  Each batch's launches go to its lane's stream in order; the HOST enqueues a group segment by
+    // segment (A.extend(s) A.shade(s) B.extend(s) B.shade(s) A.extend(s+1) ...), which changes nothing for independent streams and is what lets
+    // PHASE_LOCK tie them: B's extend of a segment waits for A's extend of that segment, A's next extend for B's — so that an issue-bound
+    // extend always runs beside the other batch's memory-bound shade (left alone, the two lanes drift INTO phase within three segments:
+    // profiles/r05a_share_trace.txt).
+    struct BatchCtx { fw::DFrame fr; fw::LaunchCfg cfg; fw::DPaths buf[2]; float2 *hits; float4 *srad; fw::DPark park; uint32_t *totals; uint32_t n_paths; int cur; int lane; hipStream_t ls; };
+    // Measured (profiles/r05j_phase_lock.txt, three interleaved pairs): cornell 33.4-33.8 -> 32.2-32.4 ms — the lock holds the frame in the faster
+    // of the two phases it otherwise lands in by chance (profiles/r05h_layout_pad.txt) —, where extend and shade last about as long as each
+    // other.  Under use_bvh an extend lasts three shades and waiting for the other batch's costs: suzanne 62.7 -> 67.7, part2 @256 119.6 ->
+    // 124.5, teapot @128 46.4 -> 47.9, random_spheres 1.64 -> 1.98.  Hence: on for the box-list scenes of the linear scan, off elsewhere.
+    const bool phase_lock = n_lanes == 2 && !fused && (O.phase_lock == 1 || (O.phase_lock < 0 && !p->use_bvh && cfg.n_defer > 0));
+    std::vector<hipEvent_t> &pe = ws->phase_events;
+    while (phase_lock && pe.size() < 2 * (size_t)fw::MAX_SEGMENTS) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); pe.push_back(e); }
+    float4 *const accum = (float4 *)ws->accum.p;
+    auto begin_batch = [&](uint32_t b, BatchCtx &c) -> int {
         const int l = (int)(b % (uint32_t)n_lanes);
         Workspace::Lane &L = ws->lanes[l];
-        hipStream_t ls = n_lanes > 1 ? L.stream : stream;
-        cfg.stream = ls;
-        cfg.q.wcount = (uint32_t *)L.wcount;
-        auto timed = [&](int cls, auto &&launch) {
-            launch();
-            if (timing) { (void)hipEventRecord(L.events[1 + ev_next[l]], ls); ev_next[l]++; ev_class[l].push_back(cls); }
-        };
-        if (timing && ev_next[l] == 0) (void)hipEventRecord(L.events[0], ls);
-        fr.sample0 = first_sample + b * spp_b;
-        fr.dep_bits = (uint32_t *)L.dep_bits;
-        fr.atten = (fr.chain_bits == 0 && exact_product && !fused_req) ? (float4 *)L.atten : nullptr; fr.atten_stride = cap;
-        if (fr.skip_zero_deposits) HIPCHK(hipMemsetAsync(fr.dep_bits, 0, ((size_t)cap + 31) / 32 * 4, ls));
+        c.lane = l; c.ls = n_lanes > 1 ? L.stream : stream;
+        c.cfg = cfg; c.cfg.stream = c.ls; c.cfg.q.wcount = (uint32_t *)L.wcount;
+        c.fr = fr;
+        if (timing && ev_next[l] == 0) (void)hipEventRecord(L.events[0], c.ls);
+        c.fr.sample0 = first_sample + b * spp_b;
+        c.fr.dep_bits = (uint32_t *)L.dep_bits;
+        c.fr.atten = (c.fr.chain_bits == 0 && exact_product && !fused_req) ? (float4 *)L.atten : nullptr; c.fr.atten_stride = cap;
+        if (c.fr.skip_zero_deposits) HIPCHK(hipMemsetAsync(c.fr.dep_bits, 0, ((size_t)cap + 31) / 32 * 4, c.ls));
         if (exact_mode) {
-            fr.ex.slots[0] = (uint32_t *)L.exact_slots; fr.ex.slots[1] = fr.ex.slots[0] + max_paths;
-            fr.ex.count = fr.ex.slots[1] + max_paths; fr.ex.cap = max_paths;
-            HIPCHK(hipMemsetAsync(fr.ex.count, 0, 64, ls));
+            c.fr.ex.slots[0] = (uint32_t *)L.exact_slots; c.fr.ex.slots[1] = c.fr.ex.slots[0] + max_paths;
+            c.fr.ex.count = c.fr.ex.slots[1] + max_paths; c.fr.ex.cap = max_paths;
+            HIPCHK(hipMemsetAsync(c.fr.ex.count, 0, 64, c.ls));
         }
-        fr.spp_batch = std::min(spp_b, p->samples - b * spp_b);
-        uint32_t n_paths = n_pix * fr.spp_batch;
-        uint32_t *totals = (uint32_t *)ws->totals.p + (size_t)b * fw::COUNT_STRIDE;
-        fw::DPaths buf[2];
-        for (int k = 0; k < 2; k++) buf[k] = {(float4 *)L.ray_a[k], (float2 *)L.ray_b[k], (float4 *)L.state[k]};
-        float2 *hits = (float2 *)L.hits;
-        float4 *srad = (float4 *)L.sample_rad, *accum = (float4 *)ws->accum.p;
-        const fw::DPark park{(float4 *)L.park_a, (float2 *)L.park_b, (float4 *)L.park_m, q.cap + 64u, (uint32_t *)L.pcount,
-                             park_meshes ? (uint32_t *)L.pcount + q.n_waves : nullptr};
-        if (park_meshes) HIPCHK(hipMemsetAsync(park.ptotal, 0, (size_t)q.n_waves * 4, ls));
-        int cur = 0;
-        timed(0, [&] { fw::launch_raygen(cfg, cam, fr, buf[cur], srad, n_paths); });
-        for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++) {
+        c.fr.spp_batch = std::min(spp_b, p->samples - b * spp_b);
+        c.n_paths = n_pix * c.fr.spp_batch;
+        c.totals = (uint32_t *)ws->totals.p + (size_t)b * fw::COUNT_STRIDE;
+        for (int k = 0; k < 2; k++) c.buf[k] = {(float4 *)L.ray_a[k], (float2 *)L.ray_b[k], (float4 *)L.state[k]};
+        c.hits = (float2 *)L.hits;
+        c.srad = (float4 *)L.sample_rad;
+        c.park = fw::DPark{(float4 *)L.park_a, (float2 *)L.park_b, (float4 *)L.park_m, q.cap + 64u, (uint32_t *)L.pcount,
+                           park_meshes ? (uint32_t *)L.pcount + q.n_waves : nullptr};
+        if (park_meshes) HIPCHK(hipMemsetAsync(c.park.ptotal, 0, (size_t)q.n_waves * 4, c.ls));
+        c.cur = 0;
+        return FW_OK;
+    };
+    auto timed = [&](BatchCtx &c, int cls, auto &&launch) {
+        launch();
+        if (timing) { (void)hipEventRecord(ws->lanes[c.lane].events[1 + ev_next[c.lane]], c.ls); ev_next[c.lane]++; ev_class[c.lane].push_back(cls); }
+    };
+    // which: index of the batch inside its group (0 or 1 under PHASE_LOCK)
+    auto segment = [&](uint32_t b, BatchCtx &c, int seg, int which, int group_size) -> int {
 #if FW_AB
-            if (fused) timed(2, [&] { fw::launch_bounce(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], srad, seg, use_bvh); });
-            else
+        if (fused) { timed(c, 2, [&] { fw::launch_bounce(c.cfg, sc->d, c.fr, c.buf[c.cur], c.buf[c.cur ^ 1], c.srad, seg, use_bvh); }); c.cur ^= 1; return FW_OK; }
 #endif
-            {
-                if (stagger && seg == 0 && b > 0) HIPCHK(hipStreamWaitEvent(ls, ws->events[3 + n_batches + b - 1], 0));   // start half a segment behind the batch before
-                timed(1, [&] { fw::launch_extend(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh, park); });
-                if (stagger && seg == 0) HIPCHK(hipEventRecord(ws->events[3 + n_batches + b], ls));
-                // the rays whose result depends on how the trees are walked (DExact), walked the reference's way: their hit records replaced
-                if (exact_mode) timed(1, [&] { fw::launch_extend_exact(cfg, sc->d, fr, buf[cur], hits, seg, use_bvh); });
-                if (dump_one) {     // debug (tools/diverge.py): the one path of this call sits in slot 0 of wave 0 in every segment
-                    float *r = &dump_rec[(size_t)seg * 16];
-                    uint32_t alive = 0;
-                    HIPCHK(hipMemcpyAsync(&alive, cfg.q.wcount + (size_t)seg * q.n_waves, 4, hipMemcpyDeviceToHost, ls));
-                    HIPCHK(hipMemcpyAsync(r, buf[cur].ray_a, 16, hipMemcpyDeviceToHost, ls));
-                    HIPCHK(hipMemcpyAsync(r + 4, buf[cur].ray_b, 8, hipMemcpyDeviceToHost, ls));
-                    HIPCHK(hipMemcpyAsync(r + 6, buf[cur].state, 16, hipMemcpyDeviceToHost, ls));
-                    HIPCHK(hipMemcpyAsync(r + 10, hits, 8, hipMemcpyDeviceToHost, ls));
-                    HIPCHK(hipStreamSynchronize(ls));
-                    r[12] = (float)alive;
-                }
-                timed(2, [&] { fw::launch_shade(cfg, sc->d, fr, buf[cur], buf[cur ^ 1], hits, srad, seg); });
-            }
-            cur ^= 1;
+        if (stagger && seg == 0 && b > 0) HIPCHK(hipStreamWaitEvent(c.ls, ws->events[3 + n_batches + b - 1], 0));   // start half a segment behind the batch before
+        if (phase_lock && group_size == 2) {
+            if (which == 1) HIPCHK(hipStreamWaitEvent(c.ls, pe[(size_t)seg], 0));                                     // B.extend(s) beside A.shade(s)
+            else if (seg > 0) HIPCHK(hipStreamWaitEvent(c.ls, pe[(size_t)fw::MAX_SEGMENTS + (size_t)seg - 1], 0));   // A.extend(s) beside B.shade(s - 1)
         }
-        timed(3, [&] { fw::launch_queue_totals(cfg, totals, park.ptotal); });       // reads this batch's queue counts: before the lane's next batch overwrites them
-        if (count_deposits) fw::launch_count_deposits(cfg, fr.dep_bits, totals + 12);   // not a kernel class: after the last timed event of its neighbours
+        timed(c, 1, [&] { fw::launch_extend(c.cfg, sc->d, c.fr, c.buf[c.cur], c.hits, seg, use_bvh, c.park); });
+        if (phase_lock && group_size == 2) HIPCHK(hipEventRecord(pe[(size_t)which * fw::MAX_SEGMENTS + (size_t)seg], c.ls));
+        if (stagger && seg == 0) HIPCHK(hipEventRecord(ws->events[3 + n_batches + b], c.ls));
+        // the rays whose result depends on how the trees are walked (DExact), walked the reference's way: their hit records replaced
+        if (exact_mode) timed(c, 1, [&] { fw::launch_extend_exact(c.cfg, sc->d, c.fr, c.buf[c.cur], c.hits, seg, use_bvh); });
+        if (dump_one) {     // debug (tools/diverge.py): the one path of this call sits in slot 0 of wave 0 in every segment
+            float *r = &dump_rec[(size_t)seg * 16];
+            uint32_t alive = 0;
+            HIPCHK(hipMemcpyAsync(&alive, c.cfg.q.wcount + (size_t)seg * q.n_waves, 4, hipMemcpyDeviceToHost, c.ls));
+            HIPCHK(hipMemcpyAsync(r, c.buf[c.cur].ray_a, 16, hipMemcpyDeviceToHost, c.ls));
+            HIPCHK(hipMemcpyAsync(r + 4, c.buf[c.cur].ray_b, 8, hipMemcpyDeviceToHost, c.ls));
+            HIPCHK(hipMemcpyAsync(r + 6, c.buf[c.cur].state, 16, hipMemcpyDeviceToHost, c.ls));
+            HIPCHK(hipMemcpyAsync(r + 10, c.hits, 8, hipMemcpyDeviceToHost, c.ls));
+            HIPCHK(hipStreamSynchronize(c.ls));
+            r[12] = (float)alive;
+        }
+        timed(c, 2, [&] { fw::launch_shade(c.cfg, sc->d, c.fr, c.buf[c.cur], c.buf[c.cur ^ 1], c.hits, c.srad, seg); });
+        c.cur ^= 1;
+        return FW_OK;
+    };
+    auto end_batch = [&](uint32_t b, BatchCtx &c) -> int {
+        timed(c, 3, [&] { fw::launch_queue_totals(c.cfg, c.totals, c.park.ptotal); });       // reads this batch's queue counts: before the lane's next batch overwrites them
+        if (count_deposits) fw::launch_count_deposits(c.cfg, c.fr.dep_bits, c.totals + 12);   // not a kernel class: after the last timed event of its neighbours
         // `total_color += color(..)` in sample order (render.rs:181): batch b is accumulated after batch b-1, whichever
         // lanes they ran on, so the image does not depend on the number of lanes or batches
-        if (n_lanes > 1 && b > 0) HIPCHK(hipStreamWaitEvent(ls, ws->events[3 + b - 1], 0));
-        timed(3, [&] { fw::launch_accumulate(cfg, fr, srad, accum); });
-        if (n_lanes > 1) HIPCHK(hipEventRecord(ws->events[3 + b], ls));
+        if (n_lanes > 1 && b > 0) HIPCHK(hipStreamWaitEvent(c.ls, ws->events[3 + b - 1], 0));
+        timed(c, 3, [&] { fw::launch_accumulate(c.cfg, c.fr, c.srad, accum); });
+        if (n_lanes > 1) HIPCHK(hipEventRecord(ws->events[3 + b], c.ls));
+        return FW_OK;
+    };
+    for (uint32_t b0 = 0; b0 < n_batches; b0 += (uint32_t)n_lanes) {
+        const int group = (int)std::min<uint32_t>((uint32_t)n_lanes, n_batches - b0);
+        BatchCtx ctx[Workspace::MAX_LANES];
+        for (int g = 0; g < group; g++) {
+            if (int brc = begin_batch(b0 + (uint32_t)g, ctx[g])) return brc;
+            timed(ctx[g], 0, [&] { fw::launch_raygen(ctx[g].cfg, cam, ctx[g].fr, ctx[g].buf[0], ctx[g].srad, ctx[g].n_paths); });
+        }
+        for (int seg = 0; seg < fw::MAX_SEGMENTS; seg++)
+            for (int g = 0; g < group; g++)
+                if (int src = segment(b0 + (uint32_t)g, ctx[g], seg, g, group)) return src;
+        for (int g = 0; g < group; g++)
+            if (int erc = end_batch(b0 + (uint32_t)g, ctx[g])) return erc;
+        fr = ctx[group - 1].fr;        // (the frame-level fields the code below reads are the same in every batch)
     }
     if (n_lanes > 1) HIPCHK(hipStreamWaitEvent(stream, ws->events[3 + n_batches - 1], 0));    // join
     cfg.stream = stream;
