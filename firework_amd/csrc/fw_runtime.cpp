@@ -1798,8 +1798,13 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     // Measured (profiles/r05j_phase_lock.txt, three interleaved pairs): cornell 33.4-33.8 -> 32.2-32.4 ms — the lock holds the frame in the faster
     // of the two phases it otherwise lands in by chance (profiles/r05h_layout_pad.txt) —, where extend and shade last about as long as each
     // other.  Under use_bvh an extend lasts three shades and waiting for the other batch's costs: suzanne 62.7 -> 67.7, part2 @256 119.6 ->
-    // 124.5, teapot @128 46.4 -> 47.9, random_spheres 1.64 -> 1.98.  Hence: on for the box-list scenes of the linear scan, off elsewhere.
-    const bool phase_lock = n_lanes == 2 && !fused && (O.phase_lock == 1 || (O.phase_lock < 0 && !p->use_bvh && cfg.n_defer > 0));
+    // 124.5, teapot @128 46.4 -> 47.9, random_spheres 1.64 -> 1.98.  And short launches pay for every wait: a rank's share of a cornell frame
+    // (profiles/r05n_share_lock.txt, each setting twice) 1/4: 8.8 ms without the lock, 10.0 with it; 1/8: 4.5 vs 5.3; 1/2 (67 M paths per
+    // batch): 16.7-16.8 vs 16.6 on one box, 16.3 vs 16.8-17.2 on another; the whole frame (134 M per batch) 33.4-33.8 vs 32.3-32.5.  Hence:
+    // on for the box-list scenes of the linear scan when a batch holds PHASE_LOCK_MIN_CHUNKS chunks of 64 paths (between the two sizes it
+    // was measured to pay and not to pay at), off elsewhere.
+    constexpr uint64_t PHASE_LOCK_MIN_CHUNKS = 3u << 19;      // 100 M paths
+    const bool phase_lock = n_lanes == 2 && !fused && (O.phase_lock == 1 || (O.phase_lock < 0 && !p->use_bvh && cfg.n_defer > 0 && chunks >= PHASE_LOCK_MIN_CHUNKS));
     std::vector<hipEvent_t> &pe = ws->phase_events;
     while (phase_lock && pe.size() < 2 * (size_t)fw::MAX_SEGMENTS) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); pe.push_back(e); }
     float4 *const accum = (float4 *)ws->accum.p;
