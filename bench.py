@@ -435,6 +435,12 @@ def roofline_objects(acc, args, tr, renderer, steps=None):
         "algorithmic_bytes_per_launch": shd_bytes / n_sh, "avg_launch_us": shd_s * 1e6 / n_sh,
         "bytes_per_ray": shd_bytes / max(1.0, float(exact["rays"])),
         "counters": shade_bound,      # what the SQ counters of this build say k_shade waits for (round 4: with the 8-byte state its instruction issue is as busy as its HBM streams)
+        # ... and what the kernel answered when asked directly (round 5, cornell): the label above is the counter rule's, the ablations do not bear it out
+        "ablations": {"source": "profiles/r05d_shade_ablations.txt, r05b_shade_pipe_ab.txt, r05l_shade_two_ahead.txt; profiles/NOTES_r05.md section 2",
+                      "minus_40pct_vector_instructions": "no change (19.3-19.4 vs 19.1-19.3 ms)", "static_vmcnt_waits": "no change",
+                      "six_waves_per_simd": "no change (19.6-19.7)", "prefetch_one_and_a_half_chunks_ahead": "no change",
+                      "streams_and_compaction_alone": "5.5 TB/s = the box's copy rate (the kernel itself: 4.1 TB/s)",
+                      "same_binary_two_processes_one_box": "17.6 and 19.4 ms: follows where the arena was placed"},
         "bytes": "this layout's streams, exact from the queue counters; zero deposits elided over a black environment are not counted "
                  f"({exact['deposits']} of {exact['samples']} radiance records written)",
         "other_kernel": {"kernel": "k_extend", "bound": other_bound, "bound_source": other_src,
