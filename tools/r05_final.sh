@@ -33,4 +33,22 @@ case $PART in
     echo "== ${sw//$V\//}"
     env $sw timeout -k 10 500 python3 -m pytest tests/test_gpu_divergence.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2 || { echo "FAILED under $sw"; exit 1; }
   done 2>&1 | tee $O/switches.txt ;;
+3b)
+  for sw in "FIREWORK_LIB=$V/lib_ab.so FIREWORK_TLAS_REFILL=0" "FIREWORK_LIB=$V/lib_ab.so FIREWORK_SHADE_LIST=1" "FIREWORK_LIB=$V/lib_ab.so FIREWORK_FUSED=1"; do
+    echo "== ${sw//$V\//}"
+    env $sw timeout -k 10 500 python3 -m pytest tests/test_gpu_divergence.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -4 || { echo "FAILED under $sw"; exit 1; }
+  done 2>&1 | tee $O/switches_b.txt ;;
+4)
+  # the last pass, on the committed build with its counter summaries under profiles/: tests, the bench line (roofline.bound and traffic from
+  # the counters), the shares, C1 repeated, C5 at its own 4096 spp against the oracle on a pixel lattice (heartbeat: the oracle leg is silent)
+  timeout -k 10 600 python3 -m pytest tests -m gpu -x -q 2>&1 | tee $O/tests.log | tail -3; echo "tests rc=$?" | tee -a $O/summary4.txt
+  timeout -k 10 400 python3 bench.py > $O/bench.json 2>$O/bench.err; echo "bench rc=$?" | tee -a $O/summary4.txt; cut -c1-300 $O/bench.json
+  for i in 1 2; do timeout -k 10 200 python3 tools/share.py 2>/dev/null; done | tee $O/share.txt
+  for i in 1 2 3; do timeout -k 10 100 python3 bench.py --config C1_random_spheres --spp 64 --steps 20 --warmup 3 --no-cpu-baseline --no-one-shot 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('C1 @64 ms', round(d['ms_per_step'],3), 'Mrays/s', round(d['value']))"; done | tee $O/c1.txt
+  ( timeout -k 10 1000 python3 bench.py --config C5_part2_all --steps 2 --warmup 1 --no-one-shot --parity-seconds 150 > $O/c5_4096.json 2> $O/c5_4096.err; echo "rc=$?" > $O/c5_rc.txt ) &
+  PID=$!
+  while kill -0 $PID 2>/dev/null; do sleep 45; echo "heartbeat $(date +%s)"; done
+  cat $O/c5_rc.txt | tee -a $O/summary4.txt
+  python3 -c "
+import json; d=json.loads(open('$O/c5_4096.json').read().strip().splitlines()[-1]); print({k: d[k] for k in ('value','ms_per_step')}); print('parity', d['parity'])" ;;
 esac
