@@ -63,7 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline and parity)")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-one-shot", action="store_true")
-    ap.add_argument("--parity-seconds", type=float, default=25.0, help="CPU budget of the parity leg (pixel lattice chosen to fit)")
+    ap.add_argument("--parity-seconds", type=float, default=45.0, help="CPU budget of the parity leg (pixel lattice chosen to fit)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (=RCCL over xGMI) for real multi-GPU runs; gloo stages the gather through host memory and "
                          "lets several ranks share one GPU — a functional rehearsal of the N>1 path on a 1-GPU box")
