@@ -42,6 +42,7 @@ struct Options {
          no_tile_order = false, no_zero_skip = false, dep_pixel_major = false, dep_slot_major = false, trace = false, no_chain = false,
          exact_product = false;   // EXACT_PRODUCT: textured scenes keep every scattering's attenuation and multiply back to front at deposit (render.rs:23-28's order)
     int streams = 0;              // STREAMS=n batches in flight (0: the library's choice)
+    int graph = -1;               // GRAPH=0|1: a frame that repeats is replayed as one hipGraph (-1: frames of small batches, whose launches are short)
     int phase_lock = -1;          // PHASE_LOCK=0|1: the two batches in flight held in anti-phase, one's extend beside the other's shade (-1: where it pays: box-list scenes)
     int soft_shear_log2 = 5, exact_shear_log2 = 10; double exact_far_x = 256.0;   // SOFT_SHEAR_LOG2 (0: off), EXACT_SHEAR_LOG2, EXACT_FAR_X: the flag rules' thresholds (tools/flag_margin.py)
     double wide_node_cost = 0.0005;   // WIDE_NODE_COST: the constant a wide node costs in the collapse, in root areas (wide_convert)
@@ -55,7 +56,7 @@ struct Options {
 #endif
 };
 const char *const OPTION_NAMES[] = {"BVH", "NO_EXACT", "EXACT_ALL", "EXACT_FORM", "NO_DEFER", "NO_HIT4", "NO_HOIST", "NO_LDS_TABLES", "NO_LDS_TREES", "NO_LDS_TRIS",
-                                    "NO_SHORT_RAYS", "NO_TILE_ORDER", "NO_ZERO_SKIP", "DEP_PIXEL_MAJOR", "DEP_SLOT_MAJOR", "NO_CHAIN", "EXACT_PRODUCT", "PHASE_LOCK", "SOFT_SHEAR_LOG2", "EXACT_SHEAR_LOG2", "EXACT_FAR_X", "WIDE_NODE_COST", "TRACE", "STREAMS", "WIDE", "WAVES",
+                                    "NO_SHORT_RAYS", "NO_TILE_ORDER", "NO_ZERO_SKIP", "DEP_PIXEL_MAJOR", "DEP_SLOT_MAJOR", "NO_CHAIN", "EXACT_PRODUCT", "PHASE_LOCK", "GRAPH", "SOFT_SHEAR_LOG2", "EXACT_SHEAR_LOG2", "EXACT_FAR_X", "WIDE_NODE_COST", "TRACE", "STREAMS", "WIDE", "WAVES",
                                     "PATHS_PER_BATCH", "DUMP_PATH",
 #if FW_AB
                                     "FUSED", "TLAS_REFILL", "SHADE_LIST", "NO_SHADE_DEFER", "STAGGER", "DEBUG_WIDE_LEVELS",
@@ -83,6 +84,7 @@ bool option_apply(Options &o, const char *name, const char *v) {      // v == nu
     else if (n == "NO_CHAIN") o.no_chain = on();
     else if (n == "EXACT_PRODUCT") o.exact_product = v && atoi(v) != 0;
     else if (n == "PHASE_LOCK") o.phase_lock = v ? (atoi(v) != 0 ? 1 : 0) : -1;
+    else if (n == "GRAPH") o.graph = v ? (atoi(v) != 0 ? 1 : 0) : -1;
     else if (n == "SOFT_SHEAR_LOG2") o.soft_shear_log2 = v ? (int)num() : 5;
     else if (n == "EXACT_SHEAR_LOG2") o.exact_shear_log2 = v ? (int)num() : 10;
     else if (n == "EXACT_FAR_X") o.exact_far_x = v ? atof(v) : 256.0;
@@ -739,6 +741,10 @@ struct Workspace {
     DevBuf scene_cache;                   // the last destroyed scene's allocation, reused by the next fw_scene_create
     std::vector<hipEvent_t> events;       // [0] frame start, [1] frame stop, [2] fork, [3..] per-batch "accumulated" events
     hipEvent_t ev_d2h = nullptr;          // after the device -> host copies of the outputs
+    // GRAPH: the launches of one frame between fork and join, captured the second time the same frame is asked for and replayed from then on.
+    // `key` is a hash of every by-value kernel argument struct of the frame (camera, frame, queue, launch configuration, scene) and of
+    // the buffers they do not name: anything that changes what a launch would be changes it, and a changed key is only ever a miss.
+    struct FrameGraph { uint64_t key = 0, seen = 0; hipGraphExec_t exec = nullptr; hipStream_t origin = nullptr; bool broken = false; fw::DFrame fr_after{}; } fg;
     std::vector<hipEvent_t> phase_events; // PHASE_LOCK: [lane-in-group][segment] "this batch's extend of the segment has finished"
     DevBuf tile_ids; uint32_t tile_w = 0, tile_h = 0;   // the library's own 16x16-tile pixel order of a (tile_w x tile_h) frame
     void *staging = nullptr; size_t staging_bytes = 0;  // pinned host memory the scene blob is assembled in (k_upload reads it)
@@ -750,6 +756,7 @@ struct Workspace {
     void release() {
         inited = false;
         if (ev_d2h) { (void)hipEventDestroy(ev_d2h); ev_d2h = nullptr; }
+        if (fg.exec) { (void)hipGraphExecDestroy(fg.exec); fg.exec = nullptr; } if (fg.origin) { (void)hipStreamDestroy(fg.origin); fg.origin = nullptr; } fg.key = fg.seen = 0; fg.broken = false;
         if (ev_upload) { (void)hipEventSynchronize(ev_upload); (void)hipEventDestroy(ev_upload); ev_upload = nullptr; }
         if (upload_stream) { (void)hipStreamDestroy(upload_stream); upload_stream = nullptr; }
         if (staging) { (void)hipHostFree(staging); staging = nullptr; staging_bytes = 0; }
@@ -1785,10 +1792,15 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     std::vector<float> dump_rec(dump_one ? (size_t)fw::MAX_SEGMENTS * 16 : 0, 0.f);
 
     HIPCHK(hipEventRecord(ws->events[0], stream));
-    if (n_lanes > 1) {     // fork: the lane streams start after everything queued on the caller's stream so far
-        HIPCHK(hipEventRecord(ws->events[2], stream));
-        for (int l = 0; l < n_lanes; l++) HIPCHK(hipStreamWaitEvent(ws->lanes[l].stream, ws->events[2], 0));
-    }
+    hipStream_t origin = stream;       // the stream the frame's launches fork from and join: the caller's, or the capture's own (GRAPH)
+    bool graph_replayed = false;       // this frame's launches went out as one hipGraphLaunch (fw_stats.reserved bit 31)
+    auto fork_lanes = [&]() -> int {
+        if (n_lanes > 1) {     // fork: the lane streams start after everything queued on the origin stream so far
+            HIPCHK(hipEventRecord(ws->events[2], origin));
+            for (int l = 0; l < n_lanes; l++) HIPCHK(hipStreamWaitEvent(ws->lanes[l].stream, ws->events[2], 0));
+        }
+        return FW_OK;
+    };
     // The batches of a frame, n_lanes at a time.  Each batch's launches go to its lane's stream in order; the HOST enqueues a group segment by
     // segment (A.extend(s) A.shade(s) B.extend(s) B.shade(s) A.extend(s+1) ...), which changes nothing for independent streams and is what lets
     // PHASE_LOCK tie them: B's extend of a segment waits for A's extend of that segment, A's next extend for B's — so that an issue-bound
@@ -1811,7 +1823,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     auto begin_batch = [&](uint32_t b, BatchCtx &c) -> int {
         const int l = (int)(b % (uint32_t)n_lanes);
         Workspace::Lane &L = ws->lanes[l];
-        c.lane = l; c.ls = n_lanes > 1 ? L.stream : stream;
+        c.lane = l; c.ls = n_lanes > 1 ? L.stream : origin;
         c.cfg = cfg; c.cfg.stream = c.ls; c.cfg.q.wcount = (uint32_t *)L.wcount;
         c.fr = fr;
         if (timing && ev_next[l] == 0) (void)hipEventRecord(L.events[0], c.ls);
@@ -1880,6 +1892,8 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         if (n_lanes > 1) HIPCHK(hipEventRecord(ws->events[3 + b], c.ls));
         return FW_OK;
     };
+    auto enqueue_frame = [&]() -> int {
+    if (int frc = fork_lanes()) return frc;
     for (uint32_t b0 = 0; b0 < n_batches; b0 += (uint32_t)n_lanes) {
         const int group = (int)std::min<uint32_t>((uint32_t)n_lanes, n_batches - b0);
         BatchCtx ctx[Workspace::MAX_LANES];
@@ -1894,7 +1908,63 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
             if (int erc = end_batch(b0 + (uint32_t)g, ctx[g])) return erc;
         fr = ctx[group - 1].fr;        // (the frame-level fields the code below reads are the same in every batch)
     }
-    if (n_lanes > 1) HIPCHK(hipStreamWaitEvent(stream, ws->events[3 + n_batches - 1], 0));    // join
+    if (n_lanes > 1) HIPCHK(hipStreamWaitEvent(origin, ws->events[3 + n_batches - 1], 0));    // join
+    return FW_OK;
+    };
+    // GRAPH: launch-bound frames (random_spheres: 37 launches of 10-80 us with ~6 us between them; a rank's eighth of a frame) replayed as
+    // one graph.  The first time a frame is asked for it runs as ever; the second time in a row it is captured (on a stream of the
+    // workspace's own: the caller's may be the legacy stream, which cannot be captured), instantiated and launched; from then on launched.
+    // Any failure on the way turns the feature off for the workspace and the frame runs as ever.
+    {
+        Workspace::FrameGraph &fg = ws->fg;
+        constexpr uint64_t GRAPH_MAX_CHUNKS = 1u << 19;      // batches below 33 M paths
+        const bool graph_ok = O.graph != 0 && !fg.broken && !timing && !dump_one && !phase_lock && !stagger && (O.graph == 1 || chunks < GRAPH_MAX_CHUNKS);   // (a capture with PHASE_LOCK's events crashed inside the runtime: the two never meet by default — the lock wants batches of 100 M paths)
+        uint64_t key = 0;
+        if (graph_ok) {
+            uint64_t h = 1469598103934665603ull;
+            auto mix = [&](const void *ptr, size_t n) { const unsigned char *b = (const unsigned char *)ptr; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+            fw::LaunchCfg kc = cfg; kc.stream = nullptr;
+            mix(&cam, sizeof cam); mix(&fr, sizeof fr); mix(&kc, sizeof kc); mix(&sc->d, sizeof sc->d); mix(&q, sizeof q);
+            const uint64_t scalars[] = {n_batches, (uint64_t)n_lanes, spp_b, first_sample, p->samples, n_pix, max_paths, cap, exact_mode, (uint64_t)park_meshes, (uint64_t)phase_lock,
+                                        (uint64_t)count_deposits, (uint64_t)exact_product, (uint64_t)use_bvh, (uint64_t)fused, (uint64_t)stagger, (uint64_t)(uintptr_t)accum, (uint64_t)(uintptr_t)ws->totals.p,
+                                        (uint64_t)(uintptr_t)ws->arena.p, (uint64_t)ws->arena.bytes};
+            mix(scalars, sizeof scalars);
+            for (int l = 0; l < n_lanes; l++) { const Workspace::Lane &L = ws->lanes[l]; const void *ptrs[] = {L.ray_a[0], L.ray_a[1], L.ray_b[0], L.ray_b[1], L.state[0], L.state[1], L.hits, L.sample_rad, L.wcount, L.park_a, L.park_b, L.park_m, L.pcount, L.dep_bits, L.exact_slots, L.atten}; mix(ptrs, sizeof ptrs); }
+            key = h | 1ull;
+        }
+        bool done = false;
+        if (graph_ok && fg.exec && fg.key == key) {
+            HIPCHK(hipGraphLaunch(fg.exec, stream));
+            fr = fg.fr_after; done = true; graph_replayed = true;
+        } else if (graph_ok && fg.seen == key) {
+            if (!fg.origin && hipStreamCreateWithFlags(&fg.origin, hipStreamNonBlocking) != hipSuccess) { fg.origin = nullptr; fg.broken = true; }
+            if (!fg.broken && hipStreamBeginCapture(fg.origin, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                origin = fg.origin;
+                if (O.trace) fprintf(stderr, "[firework] GRAPH: capturing (%u batches, %d lanes, phase lock %d)\n", n_batches, n_lanes, (int)phase_lock);
+                const int crc = enqueue_frame();
+                origin = stream;
+                hipGraph_t g = nullptr;
+                const hipError_t ee = hipStreamEndCapture(fg.origin, &g);
+                if (O.trace) fprintf(stderr, "[firework] GRAPH: capture ended: enqueue %d, end %s\n", crc, hipGetErrorString(ee));
+                if (fg.exec) { (void)hipGraphExecDestroy(fg.exec); fg.exec = nullptr; fg.key = 0; }
+                if (crc == FW_OK && ee == hipSuccess && g && hipGraphInstantiate(&fg.exec, g, nullptr, nullptr, 0) == hipSuccess) {
+                    fg.key = key; fg.fr_after = fr;
+                    (void)hipGraphDestroy(g);
+                    if (O.trace) fprintf(stderr, "[firework] GRAPH: instantiated\n");
+                    HIPCHK(hipGraphLaunch(fg.exec, stream));
+                    if (O.trace) fprintf(stderr, "[firework] GRAPH: launched\n");
+                    graph_replayed = true;
+                    done = true;
+                } else {
+                    if (g) (void)hipGraphDestroy(g);
+                    fg.exec = nullptr; fg.broken = true; (void)hipGetLastError();
+                    if (O.trace) fprintf(stderr, "[firework] GRAPH: capture failed (%d, %s): frames run as plain launches from here on\n", crc, hipGetErrorString(ee));
+                }
+            } else { fg.broken = true; (void)hipGetLastError(); }
+        }
+        if (graph_ok) fg.seen = key;
+        if (!done) { if (int frc = enqueue_frame()) return frc; }
+    }
     cfg.stream = stream;
     fw::launch_resolve(cfg, fr, (const float4 *)ws->accum.p, first_sample + p->samples, p->gamma, d_rgb8, d_gamma, d_linear);
     if (user_accum) HIPCHK(hipMemcpyAsync(user_accum, ws->accum.p, (size_t)n_pix * 16, p->outputs_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, stream));
@@ -2000,7 +2070,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
         }
         stats->n_extend_launches = fused ? 0 : n_batches * fw::MAX_SEGMENTS; stats->n_shade_launches = n_batches * fw::MAX_SEGMENTS;
         stats->n_batches = n_batches; stats->tlas_nodes = sc->tlas_nodes; stats->blas_nodes = sc->blas_nodes;
-        stats->reserved = (sc->tlas_depth << 16) | sc->blas_depth;   // depths of the trees actually walked
+        stats->reserved = ((sc->tlas_depth & 0x7fffu) << 16) | (sc->blas_depth & 0xffffu) | (graph_replayed ? 0x80000000u : 0u);   // depths of the trees actually walked; bit 31: the frame ran as a hipGraph (GRAPH)
     }
     return FW_OK;
 }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FW_ABI_VERSION 7   /* 7: + fw_init (loading the library no longer touches the GPU); options EXACT_PRODUCT; 6: + fw_set_option (the runtime switches leave the environment: read once at load), fw_selftest_wide_bvh; 3: + fw_render_progressive; 4: fw_stats carries this layout's own HBM bytes per kernel class and the one-shot timings;
+#define FW_ABI_VERSION 7   /* 7: + fw_init (loading the library no longer touches the GPU); options EXACT_PRODUCT, PHASE_LOCK, GRAPH; 6: + fw_set_option (the runtime switches leave the environment: read once at load), fw_selftest_wide_bvh; 3: + fw_render_progressive; 4: fw_stats carries this layout's own HBM bytes per kernel class and the one-shot timings;
                               5: + fw_selftest_libm; the 4th float of an accumulation record counts the path segments of the samples that deposited */
 
 /* ---- status codes ------------------------------------------------------ */
@@ -220,7 +220,7 @@ typedef struct fw_stats {
     uint32_t n_extend_launches, n_shade_launches, n_batches;  /* FIREWORK_FUSED=1: no extend launches, the fused
                                                                  intersect+shade launches are counted and timed as shade */
     uint32_t tlas_nodes, blas_nodes;
-    uint32_t reserved;
+    uint32_t reserved;                       /* bits 0-15 / 16-30: depth of the BLAS / TLAS walked; bit 31: this frame's launches were replayed as one hipGraph (option GRAPH) */
     /* HBM bytes THIS layout has to move, per kernel class, exact from the queue counters (DESIGN.md §5 gives the per-ray
        figures; SURVEY's generic 160 B/ray formula stays in algorithmic_bytes): what roofline fractions are computed from. */
     uint64_t bytes_raygen, bytes_extend, bytes_shade, bytes_accumulate;
@@ -320,6 +320,9 @@ int fw_selftest_libm(int device, int fn, uint32_t n, const float *x, const float
      EXACT_PRODUCT=1       scenes with a varying texture keep every scattering's attenuation (16 B per segment) and multiply back to front when
                            a path deposits — render.rs:23-28's own association, the pre-gamma means then equal the CPU oracle's bit for bit
                            (scenes of constant textures always do: their 8-byte chain state).  Default off: the running product, ~1 ulp away
+     PHASE_LOCK=0|1        the two batches in flight tied in anti-phase by one event per segment (default: big box-list batches)
+     GRAPH=0|1             a frame asked for twice in a row is captured into a hipGraph and replayed from then on (default: frames of
+                           small batches, whose launches are short); fw_stats.reserved bit 31 reports a replay
      TRACE, DUMP_PATH=file                            host-side timing trace; one path's records (tools/diverge.py)
    Returns FW_ERR_BAD_ARG for a name this build does not know. */
 int fw_set_option(const char *name, const char *value);

@@ -443,6 +443,29 @@ def test_deferred_boxes_of_the_linear_scan_are_bit_identical(oracle, monkeypatch
         assert gpu.stats["rays_per_depth"] == cpu.stats["rays_per_depth"]
 
 
+def test_a_repeated_frame_replayed_as_a_graph_is_the_same_frame(oracle, monkeypatch):
+    """GRAPH: the second time in a row the same frame is asked for, its launches between fork and join are captured into a hipGraph; from
+    the third time on they are replayed (fw_stats.reserved bit 31).  Same kernels, same dependencies: the frames and the ray counts are
+    those of plain launches and of the oracle; a change of any argument (here: the seed) is a miss, never a stale replay."""
+    for name, w, h, spp in (("C1_random_spheres", 100, 56, 8), ("C3_suzanne", 96, 54, 4), ("C4b_volume_test", 64, 64, 4)):
+        s, r = scenes.config(name, w, h, spp)
+        ds = _lib.DeviceScene(s.to_desc(), 0)              # a scene that stays in HBM (a one-shot render uploads a new one every time: never the same frame twice)
+        monkeypatch.setenv("FIREWORK_GRAPH", "0")
+        plain = ds.render(r)
+        assert not plain.stats["reserved"] >> 31
+        monkeypatch.setenv("FIREWORK_GRAPH", "1")
+        frames = [ds.render(r) for _ in range(5)]
+        flags = [f.stats["reserved"] >> 31 for f in frames]
+        assert flags[0] == 0 and flags[-2:] == [1, 1], (name, flags)       # as ever first; captured + launched once the same key has been seen twice, then replayed
+        for f in frames:
+            assert np.array_equal(f.rgb8, plain.rgb8) and np.array_equal(f.linear, plain.linear) and f.stats["rays_per_depth"] == plain.stats["rays_per_depth"]
+        other = ds.render(r.seed(r.settings["seed"] + 1))                                  # another frame: not a replay, and not the old one
+        assert not other.stats["reserved"] >> 31 and not np.array_equal(other.linear, plain.linear)
+        cpu = oracle.render(s, r)
+        assert np.array_equal(other.rgb8, cpu.rgb8) and other.stats["rays_per_depth"] == cpu.stats["rays_per_depth"]
+        monkeypatch.delenv("FIREWORK_GRAPH", raising=False)
+
+
 def test_device_error_word_turns_a_stack_overflow_into_a_status_code(monkeypatch):
     """A/B build only (make ab): the wide walks check every push against the LDS levels their launch reserved, and a wave that stops
     making progress leaves its loop; either sets the device's error word and the render returns FW_ERR_HIP instead of a frame

@@ -27,5 +27,5 @@ for n in [int(x) for x in os.environ.get("BIG_MESH_N", "101,317,709").split(",")
     t0 = time.time(); ds = _lib.DeviceScene(sc.to_desc()); t1 = time.time()
     res = ds.render(r); t2 = time.time()
     st = res.stats
-    print(f"tris={mesh.num_tris()} create={t1-t0:.2f}s render={st['ms_render']:.1f}ms rays={st['rays']} Mrays/s={st['rays']/st['ms_render']/1e3:.0f} depth tlas/blas={st['reserved']>>16}/{st['reserved']&0xffff} blas_nodes(ref)={st['blas_nodes']}", flush=True)
+    print(f"tris={mesh.num_tris()} create={t1-t0:.2f}s render={st['ms_render']:.1f}ms rays={st['rays']} Mrays/s={st['rays']/st['ms_render']/1e3:.0f} depth tlas/blas={(st['reserved']>>16)&0x7fff}/{st['reserved']&0xffff} blas_nodes(ref)={st['blas_nodes']}", flush=True)
     ds.close()
