@@ -12,7 +12,7 @@ print(json.dumps({'config': d['config']['workload'], 'Mrays/s': round(d['value']
   'other_kernel': {'kernel': o.get('kernel'), 'bound': o.get('bound'), 'bound_source': o.get('bound_source'), 'counters': o.get('counters'), 'achieved_GBps': round(o.get('achieved',0)), 'frac_of_8TBps': round(o.get('frac', o.get('frac_hbm',0)),3), 'avg_launch_us': round(o.get('avg_launch_us',0),1)},
   'roofline_frame_layout_frac': round(d.get('roofline_frame',{}).get('layout',{}).get('frac',0),3), 'device': {a: b for a,b in d.get('device',{}).items() if a in ('name','sclk_mhz','mclk_mhz','copy_GBps')}}))"
 }
-run C1_random_spheres 3 1
+run C1_random_spheres 50 5      # (a frame this short is replayed as a graph from its third repetition on: GRAPH)
 run C2_cornell_box 3 1
 run C3_suzanne 2 1
 run C4a_hdri_test 2 1
