@@ -447,6 +447,7 @@ def test_a_repeated_frame_replayed_as_a_graph_is_the_same_frame(oracle, monkeypa
     """GRAPH: the second time in a row the same frame is asked for, its launches between fork and join are captured into a hipGraph; from
     the third time on they are replayed (fw_stats.reserved bit 31).  Same kernels, same dependencies: the frames and the ray counts are
     those of plain launches and of the oracle; a change of any argument (here: the seed) is a miss, never a stale replay."""
+    monkeypatch.delenv("FIREWORK_PHASE_LOCK", raising=False)       # (the switch matrix forces the lock on; a locked frame is never captured)
     for name, w, h, spp in (("C1_random_spheres", 100, 56, 8), ("C3_suzanne", 96, 54, 4), ("C4b_volume_test", 64, 64, 4)):
         s, r = scenes.config(name, w, h, spp)
         ds = _lib.DeviceScene(s.to_desc(), 0)              # a scene that stays in HBM (a one-shot render uploads a new one every time: never the same frame twice)
