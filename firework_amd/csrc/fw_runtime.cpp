@@ -1607,7 +1607,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     n_lanes = (int)std::min<uint32_t>((uint32_t)n_lanes, n_batches);
 
     // wave-private queues: many more waves than are resident, each owning >= 8 chunks of 64 paths when the batch allows
-    fw::DQueue q;
+    fw::DQueue q{};
     // How many: whole rounds of resident waves for BOTH queue kernels (k_extend_linear holds 7 waves per SIMD, k_extend_bvh 5,
     // k_shade 4 -> multiples of lcm x SIMDs), and 16-50 chunks per wave so that the half-empty last chunk of a queue stays
     // small; measured on cornell (tools/waves_sweep.sh): whole frame 86 016 waves 41.1 ms vs 131 072: 42.0; the 1/4 share of
@@ -1707,7 +1707,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     else HIPCHK(hipMemsetAsync(ws->accum.p, 0, (size_t)n_pix * 16, stream));
     HIPCHK(hipMemsetAsync(ws->totals.p, 0, (size_t)n_batches * fw::COUNT_STRIDE * 4, stream));
 
-    fw::LaunchCfg cfg;
+    fw::LaunchCfg cfg{};
     cfg.q = q;
     int max_blocks = sc->n_cus * 8;
     cfg.blocks_other = (int)std::max<uint64_t>(1, std::min<uint64_t>(((uint64_t)n_pix + fw::BLOCK - 1) / fw::BLOCK, (uint64_t)max_blocks));
@@ -1743,7 +1743,7 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
 #endif
 
     fw::DCamera cam = make_camera(p->camera, p->width, p->height);
-    fw::DFrame fr;
+    fw::DFrame fr{};         // (zeroed: the frame graph's key hashes these structs, padding and not-yet-set per-batch fields included)
     fr.width = p->width; fr.height = p->height; fr.n_pixels = n_pix; fr.inv_n_pixels = 1.0f / (float)n_pix; fr.inv_width = 1.0f / (float)p->width;
     fr.pixel_ids = p->pixel_ids ? (const uint32_t *)ws->pixel_ids.p : (own_order ? (const uint32_t *)ws->tile_ids.p : nullptr);
     fr.scatter_out = own_order ? 1u : 0u;
