@@ -7,15 +7,15 @@ from firework_amd import scenes
 from firework_amd.tiles import TiledRenderer
 
 scene, renderer = scenes.config("C2_cornell_box", None, None, None)
-renderer.time_kernels(True)
+renderer.time_kernels(os.environ.get("SHARE_NO_TIMING") != "1")      # SHARE_NO_TIMING=1: no per-launch events (ext/shd read 0): the frame as bench.py's timed loop runs it, graph replay included
 base = None
 for world in [int(x) for x in os.environ.get("SHARE_WORLDS", "1,2,4,8").split(",")]:
     tr = TiledRenderer(scene, renderer, 0, world, 0, dist=None)
     tr.tg.world = 1; tr.tg.collective = False   # no collective: assemble() just scatters the local tiles
     tr.tg.all_ids_dev = [tr.tg.all_ids_dev[0]]
-    for _ in range(2): tr.render_frame()
+    for _ in range(int(os.environ.get("SHARE_WARMUP", "2"))): tr.render_frame()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    n = 5
+    n = int(os.environ.get("SHARE_FRAMES", "5"))
     for _ in range(n): tr.render_frame()
     torch.cuda.synchronize(); ms = (time.perf_counter() - t0) * 1e3 / n
     st = tr.last_stats
