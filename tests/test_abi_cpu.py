@@ -100,3 +100,25 @@ def test_fw_init_without_a_device_fails_loudly():
     assert lib.fw_init(0, 0) == A.FW_ERR_NO_DEVICE
     with pytest.raises(_lib.FireworkError):
         _lib.init()
+
+
+def test_every_option_the_header_names_is_known_to_the_library_and_nothing_else():
+    """fw_set_option (ABI v6+) without a device: each switch named in the header's list is accepted (value NULL = back to its default), a
+    name the build does not know is FW_ERR_BAD_ARG with the name in fw_last_error() — the list in include/firework_hip.h stays the list."""
+    import re
+    from firework_amd import _abi as A, _lib
+    text = open(os.path.join(ROOT, "include", "firework_hip.h")).read()
+    block = text[text.index("except the diagnostics NO_EXACT / EXACT_ALL.  Names:"):text.index("Returns FW_ERR_BAD_ARG for a name this build does not know")]
+    names = set()
+    for line in block.split("Names:")[1].splitlines():          # "     NAME=value, OTHER_NAME      what it does": the names are the first column
+        first = re.split(r"\s{2,}", line.strip())[0]
+        if re.match(r"[A-Z][A-Z0-9_]{2,}", first):
+            names |= set(re.findall(r"\b[A-Z][A-Z0-9_]{2,}\b", first))
+    names = sorted(names)
+    assert {"BVH", "WIDE", "STREAMS", "EXACT_PRODUCT", "PHASE_LOCK", "GRAPH", "TRACE", "DUMP_PATH", "NO_CHAIN"} <= set(names), names
+    lib = _lib.load()
+    for n in names:
+        assert lib.fw_set_option(n.encode(), None) == A.FW_OK, n
+    assert lib.fw_set_option(b"NO_SUCH_SWITCH", b"1") == A.FW_ERR_BAD_ARG
+    assert b"NO_SUCH_SWITCH" in lib.fw_last_error()
+    assert lib.fw_set_option(None, None) == A.FW_OK          # back to what the environment said at load time
