@@ -258,7 +258,7 @@ template <class T> __device__ __forceinline__ T qld(const T *p) { if (FW_NT_LD) 
 
 // Camera rays of a pinhole camera (aperture 0) all start at the camera position (camera.rs:109-116 adds an offset of
 // exactly 0), so segment 0 stores only the direction, in ray_a, and ray_b is neither written nor read: 8 B less per
-// access, three accesses per sample.  The host sets pinhole0 only when no coordinate of the position is a zero (-0 + 0 = +0).
+// access, three accesses per sample.  The host sets pinhole0 only when no coordinate of the position is a negative zero (-0 + 0 = +0).
 __device__ __forceinline__ bool short_rays(const DFrame &f, int segment) { return segment == 0 && f.pinhole0 != 0u; }
 __device__ __forceinline__ float2 load_ray_b(const DPaths &in, uint32_t i, const DFrame &f, int segment) {
     if (short_rays(f, segment)) return make_float2(0.f, 0.f);

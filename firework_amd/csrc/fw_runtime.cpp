@@ -1750,7 +1750,10 @@ int render_impl(fw_scene *sc, const fw_render_params *p, uint8_t *rgb8, float *g
     fr.seed32 = (uint32_t)p->seed ^ ((uint32_t)(p->seed >> 32) * 0x9E3779B9u);
     fr.q_n_waves = q.n_waves; fr.q_shift = q.cpw_shift;
     fr.cam_pos[0] = cam.position[0]; fr.cam_pos[1] = cam.position[1]; fr.cam_pos[2] = cam.position[2];
-    fr.pinhole0 = (cam.lens_radius == 0.f && cam.position[0] != 0.f && cam.position[1] != 0.f && cam.position[2] != 0.f &&
+    // (what must not occur in the position is a NEGATIVE zero: -0 + (+0) = +0 is not the position any more, while +0 + (+-0) = +0 is.  Until round 5
+    //  this read "!= 0.f", which kept hdri_test's and volume_test's cameras — at x = 0.0 — on 24-byte camera rays)
+    auto not_negative_zero = [](float x) { uint32_t b; std::memcpy(&b, &x, 4); return b != 0x80000000u; };
+    fr.pinhole0 = (cam.lens_radius == 0.f && not_negative_zero(cam.position[0]) && not_negative_zero(cam.position[1]) && not_negative_zero(cam.position[2]) &&
                    !O.no_short_rays) ? 1u : 0u;
     // 4-byte hit records where k_shade can recompute t cheaply and exactly: the linear scan over spheres, rects and Rect3d
     fr.hit4 = (!p->use_bvh && sc->simple_shapes && !exact_mode && !O.no_hit4 && !fused_req) ? 1u : 0u;
