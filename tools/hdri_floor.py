@@ -2,7 +2,7 @@
 per segment, the bytes the counters saw against the queue streams that segment moves, and what is left per path that ENDS in the
 segment (HdrEnvironment lookup of a 16-byte texel + the 16-byte radiance record).
     python3 tools/hdri_floor.py gpurun_out/r05z_c4a profiles/r05z_full_parity.jsonl C4a_hdri_test > profiles/r05z_c4a_floor.txt"""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 d, parity, cfg = sys.argv[1], sys.argv[2], sys.argv[3]
 rays = None
 for l in open(parity):
@@ -12,7 +12,7 @@ for l in open(parity):
             rays = j["rays_per_depth_gpu"]
 def per_dispatch(sub, scale):
     rows = []
-    for f in glob.glob(f"{d}/{sub}/*/*counter_collection.csv"):
+    for f in sorted(glob.glob(f"{d}/{sub}/*/*counter_collection.csv"), key=os.path.getmtime)[-1:]:      # gpurun merges runs additively: the newest
         for r in csv.DictReader(open(f)):
             if "k_shade" in r["Kernel_Name"]:
                 rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"]) * 1024 * scale))
@@ -23,7 +23,7 @@ wr = per_dispatch("write", 1.0)
 n_seg = len(rays)
 n_batches = len(rd) // n_seg          # of all the frames the profiled command rendered (timed, exclusive pass, counting pass ...)
 n_frames = 0
-for f in glob.glob(f"{d}/fetch/*/*kernel_trace.csv"):
+for f in sorted(glob.glob(f"{d}/fetch/*/*kernel_trace.csv"), key=os.path.getmtime)[-1:]:
     n_frames += sum(1 for r in csv.DictReader(open(f)) if "k_resolve" in r["Kernel_Name"])
 print(f"# {cfg}: {len(rd)} k_shade dispatches = {n_frames} frames x {n_batches // n_frames} batches x {n_seg} segments (STREAMS=1); bytes per frame = sums over its batches, averaged over the frames")
 print(f"# streams = rays in x (ray_a 16 + ray_b 8 + state 8 + hit 8) + rays out x (ray_a 16 + ray_b 8 + state 8); segment 0 reads no ray_b/state")
