@@ -28,7 +28,7 @@ case $PART in
   timeout -k 10 500 python3 tools/fuzz_many.py 20000 600 2>&1 | tail -3 | tee $O/fuzz.txt
   kill $HB ;;
 3)
-  for sw in "FIREWORK_STREAMS=1" "FIREWORK_NO_LDS_TREES=1" "FIREWORK_WIDE=0" "FIREWORK_WIDE=q8" "FIREWORK_BVH=median" "FIREWORK_NO_LDS_TRIS=1" "FIREWORK_STREAMS=4" "FIREWORK_NO_HOIST=1" "FIREWORK_NO_CHAIN=1" "FIREWORK_NO_DEFER=1" "FIREWORK_EXACT_ALL=1" "FIREWORK_EXACT_PRODUCT=1" "FIREWORK_PHASE_LOCK=1" "FIREWORK_GRAPH=1" \
+  for sw in "FIREWORK_STREAMS=1" "FIREWORK_NO_LDS_TREES=1" "FIREWORK_WIDE=0" "FIREWORK_WIDE=q8" "FIREWORK_BVH=median" "FIREWORK_NO_LDS_TRIS=1" "FIREWORK_STREAMS=4" "FIREWORK_NO_HOIST=1" "FIREWORK_NO_CHAIN=1" "FIREWORK_NO_DEFER=1" "FIREWORK_EXACT_ALL=1" "FIREWORK_EXACT_PRODUCT=1" "FIREWORK_PHASE_LOCK=1" "FIREWORK_GRAPH=1" "FIREWORK_NO_SHORT_RAYS=1" \
             "FIREWORK_LIB=$V/lib_ab.so FIREWORK_TLAS_REFILL=0" "FIREWORK_LIB=$V/lib_ab.so FIREWORK_SHADE_LIST=1" "FIREWORK_LIB=$V/lib_ab.so FIREWORK_FUSED=1"; do
     echo "== ${sw//$V\//}"
     env $sw timeout -k 10 500 python3 -m pytest tests/test_gpu_divergence.py tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2 || { echo "FAILED under $sw"; exit 1; }
