@@ -467,6 +467,22 @@ def test_a_repeated_frame_replayed_as_a_graph_is_the_same_frame(oracle, monkeypa
         monkeypatch.delenv("FIREWORK_GRAPH", raising=False)
 
 
+def test_camera_positions_with_zeros_of_either_sign(oracle):
+    """A pinhole camera's rays all start at the camera position, so segment 0 stores 16 bytes per ray (the direction) instead of 24 — as long as
+    `position + (+-0)` is the position, bit for bit: true for every coordinate except a NEGATIVE zero (-0 + +0 = +0; camera.rs:109-116 adds the
+    lens offset even when the aperture is 0).  +0.0 coordinates (hdri_test, volume_test stand at x = 0.0) take the 16-byte form since round 5, a
+    -0.0 coordinate keeps the 24-byte one; either way the frame is the oracle's."""
+    from firework_amd.api import CameraSettings
+    s, r = scenes.config("C4b_volume_test", 48, 48, 4)
+    for pos, short in (((0.0, 2.0, -10.0), True), ((0.0, 0.0, -10.0), True), ((-0.0, 2.0, -10.0), False), ((3.0, -0.0, -10.0), False), ((3.0, 2.0, -10.0), True)):
+        r.camera(CameraSettings.default().cam_pos(pos).look_at((0.0, 0.0, 0.0)))
+        gpu, cpu = r.render_full(s), oracle.render(s, r)
+        assert np.array_equal(gpu.rgb8, cpu.rgb8) and gpu.stats["rays_per_depth"] == cpu.stats["rays_per_depth"], pos
+        assert np.array_equal(gpu.linear, cpu.linear), pos           # volume_test: constant textures only, the chain state: means bit for bit
+        per_sample = gpu.stats["bytes_raygen"] / gpu.stats["samples"]
+        assert per_sample in ((16, 20) if short else (24, 28)), (pos, per_sample)     # (+ 4 bytes where the frame is traced in the library's own tile order)
+
+
 def test_device_error_word_turns_a_stack_overflow_into_a_status_code(monkeypatch):
     """A/B build only (make ab): the wide walks check every push against the LDS levels their launch reserved, and a wave that stops
     making progress leaves its loop; either sets the device's error word and the render returns FW_ERR_HIP instead of a frame
