@@ -219,7 +219,8 @@ def main():
             # The timed loop runs the library's own schedule (two batches in flight where that is faster: their kernels overlap, so
             # their HIP-event times do too).  The roofline divides by a kernel's OWN time: a labelled exclusive pass, one batch in flight.
             ex_acc, ex_ms = exclusive_pass(tr, keys, frames=max(2, min(5, args.steps)))
-            overlapped = (ex_acc["ms_extend"] + ex_acc["ms_shade"] + ex_acc["ms_raygen"] + ex_acc["ms_accumulate"]) / ex_acc["frames"] > 1.02 * acc["ms_render"] / args.steps
+            # the library keeps two batches in flight whenever a frame has two (fw_runtime.cpp: n_lanes) unless STREAMS says otherwise
+            overlapped = int(tr.last_stats.get("n_batches", 1)) >= 2 and os.environ.get("FIREWORK_STREAMS", "") != "1"
             out["schedule"] = {"timed_loop": "two batches in flight on two streams (kernel times overlap)" if overlapped else "one batch in flight",
                                "timed_loop_ms_per_step": ms_step, "exclusive_pass_ms_per_step": ex_ms,
                                "exclusive_pass": f"FIREWORK_STREAMS=1, {ex_acc['frames']} frames after the timed loop: every kernel's HIP-event time is its own; "
